@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/: seeded synthetic inputs + golden SAMs from the REAL reference.
+
+Runs only in the build container (needs /root/reference to build oracle/_ref/basal through
+oracle/Makefile.ref).  For every fixture in FIXTURES it
+  1. generates <name>.fa.gz / <name>.fq.gz (and <name>_2.fq.gz for PE) with tools/gen_synth.py,
+  2. runs the unmodified reference binary with `-p 1 -S <seed>` on them,
+  3. stores the SAM (minus the @PG line, which embeds argv) as <name>.sam.gz,
+and writes manifest.json with the exact flags.  Only data (inputs and expected outputs) is
+committed; no reference source or binary enters the repo.
+"""
+import gzip
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "basal")
+GEN = os.path.join(ROOT, "tools", "gen_synth.py")
+
+# name -> (gen_synth args, basal flags).  -s 12 keeps the 3^k tables small so the CPU test
+# suite stays fast; c1_s16 and acgt_s16 exercise the default seed size.
+FIXTURES = {
+    # config 1 of BASELINE.json, verbatim shape (1 k x 100 bp, 1 Mb, C:T)
+    "c1_s16": (["--ref-bp", "1000000", "--contigs", "2", "--reads", "1000", "-M", "C:T"],
+               ["-M", "C:T", "-S", "1"]),
+    "ct_basic": (["--ref-bp", "300000", "--contigs", "3", "--reads", "500", "-M", "C:T", "--max-sub", "6"],
+                 ["-M", "C:T", "-S", "1", "-s", "12"]),
+    # both chains, N's in reads and reference, junk reads, lower-case reference, -u -R
+    "ct_n1_dirty": (["--ref-bp", "300000", "--contigs", "3", "--reads", "500", "-M", "C:T", "--n-frac", "0.3",
+                     "--junk-frac", "0.1", "--n-run-every", "20011", "--n-run-len", "37", "--lower-frac", "0.2",
+                     "--max-sub", "8"],
+                    ["-M", "C:T", "-S", "7", "-s", "12", "-n", "1", "-u", "-R"]),
+    "ct_pbat": (["--ref-bp", "200000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--pbat"],
+                ["-M", "C:T", "-S", "1", "-s", "12", "-n", "2"]),
+    "ag_se": (["--ref-bp", "300000", "--contigs", "2", "--reads", "500", "-M", "A:G", "--p-conv", "0.9"],
+              ["-M", "A:G", "-S", "1", "-s", "12"]),
+    # multi-way rule + gaps (config 4 family)
+    "acgt_g2": (["--ref-bp", "300000", "--contigs", "2", "--reads", "500", "-M", "A:CGT", "--p-conv", "0.3",
+                 "--indel-frac", "0.3", "--indel-max", "2"],
+                ["-M", "A:CGT", "-S", "1", "-s", "12", "-g", "2"]),
+    "acgt_s16": (["--ref-bp", "400000", "--contigs", "2", "--reads", "300", "-M", "A:CGT", "--p-conv", "0.3",
+                  "--indel-frac", "0.2", "--indel-max", "2"],
+                 ["-M", "A:CGT", "-S", "1", "-g", "2", "-n", "1"]),
+    # deletion-induced (config 5 family): plain, and the BID-seq pipeline flags
+    "tdel_g0": (["--ref-bp", "300000", "--contigs", "2", "--reads", "500", "-M", "T:-", "--p-conv", "0.02"],
+                ["-M", "T:-", "-S", "1", "-s", "12"]),
+    "tdel_pipeline": (["--ref-bp", "300000", "--contigs", "2", "--reads", "500", "-M", "T:-", "--p-conv", "0.02",
+                       "--indel-frac", "0.2", "--indel-max", "3"],
+                      ["-M", "T:-", "-S", "1", "-s", "12", "-n", "1", "-g", "3", "-R", "-u"]),
+    "gact_del": (["--ref-bp", "300000", "--contigs", "2", "--reads", "400", "-M", "G:ACT-", "--p-conv", "0.2"],
+                 ["-M", "G:ACT-", "-S", "3", "-s", "12", "-g", "1", "-n", "1"]),
+    # C:T with gaps on both strands
+    "ct_g3": (["--ref-bp", "300000", "--contigs", "2", "--reads", "500", "-M", "C:T", "--indel-frac", "0.5",
+               "--indel-max", "3"],
+              ["-M", "C:T", "-S", "1", "-s", "12", "-g", "3", "-n", "1"]),
+    # repeats: 150-copy family; caps, threshold tightening, -r 0/1/2
+    "rep_r1": (["--ref-bp", "400000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--repeat-copies", "150",
+                "--repeat-len", "400", "--max-sub", "4"],
+               ["-M", "C:T", "-S", "1", "-s", "12", "-k", "1e-3"]),
+    "rep_r2_w10": (["--ref-bp", "400000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--repeat-copies", "150",
+                    "--repeat-len", "400", "--max-sub", "4"],
+                   ["-M", "C:T", "-S", "5", "-s", "12", "-k", "1e-3", "-r", "2", "-w", "10", "-n", "1"]),
+    "rep_r0_u": (["--ref-bp", "400000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--repeat-copies", "150",
+                  "--repeat-len", "400", "--max-sub", "4"],
+                 ["-M", "C:T", "-S", "1", "-s", "12", "-k", "1e-3", "-r", "0", "-u"]),
+    "rep_g2": (["--ref-bp", "400000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--repeat-copies", "150",
+                "--repeat-len", "400", "--max-sub", "3", "--indel-frac", "0.3"],
+               ["-M", "C:T", "-S", "2", "-s", "12", "-k", "1e-3", "-g", "2", "-w", "20", "-r", "2"]),
+    # variable read lengths (incl. lengths where (len-I+1)%k==0 -> stale start offset), trimming
+    "varlen_trim": (["--ref-bp", "300000", "--contigs", "2", "--reads", "600", "-M", "C:T", "--len", "131",
+                     "--len-jitter", "100"],
+                    ["-M", "C:T", "-S", "1", "-s", "12", "-u", "-L", "120"]),
+    "varlen_s16": (["--ref-bp", "300000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--len", "150",
+                    "--len-jitter", "60"],
+                   ["-M", "C:T", "-S", "1", "-n", "1"]),
+    # -v forms, -I, -s 10
+    "v_abs3": (["--ref-bp", "200000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--max-sub", "6"],
+               ["-M", "C:T", "-S", "1", "-s", "12", "-v", "3", "-u"]),
+    "v_frac05_I2": (["--ref-bp", "200000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--max-sub", "6"],
+                    ["-M", "C:T", "-S", "1", "-s", "10", "-I", "2", "-v", "0.05", "-u"]),
+    "v0": (["--ref-bp", "200000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--max-sub", "1"],
+           ["-M", "C:T", "-S", "1", "-s", "12", "-v", "0", "-u"]),
+    # transcriptome-like: many short contigs, 150 bp reads, A:G
+    "tx_ag_150": (["--ref-bp", "600000", "--contigs", "300", "--reads", "400", "-M", "A:G", "--p-conv", "0.9",
+                   "--len", "150"],
+                  ["-M", "A:G", "-S", "1", "-s", "12", "-n", "1"]),
+    # FASTA reads input
+    "fa_reads": (["--ref-bp", "200000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--fasta-reads"],
+                 ["-M", "C:T", "-S", "1", "-s", "12"]),
+}
+
+PE_FIXTURES = {
+    "pe_ag_150": (["--ref-bp", "600000", "--contigs", "40", "--reads", "400", "-M", "A:G", "--p-conv", "0.9",
+                   "--len", "150", "--rev-frac", "0.5"],
+                  ["-M", "A:G", "-S", "1", "-s", "12"]),
+    "pe_ct_100_u": (["--ref-bp", "400000", "--contigs", "2", "--reads", "400", "-M", "C:T", "--len", "100",
+                     "--junk-frac", "0.1", "--max-sub", "8"],
+                    ["-M", "C:T", "-S", "1", "-s", "12", "-u", "-R"]),
+    "pe_rep_r2": (["--ref-bp", "400000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--repeat-copies", "150",
+                   "--repeat-len", "700", "--max-sub", "3"],
+                  ["-M", "C:T", "-S", "1", "-s", "12", "-k", "1e-3", "-r", "2", "-w", "20", "-u"]),
+    "pe_g2_n1": (["--ref-bp", "300000", "--contigs", "2", "--reads", "300", "-M", "A:CGT", "--p-conv", "0.3",
+                  "--indel-frac", "0.3"],
+                 ["-M", "A:CGT", "-S", "1", "-s", "12", "-g", "2", "-n", "1", "-u"]),
+}
+
+
+def gz_write(path, data):
+    with open(path, "wb") as raw:
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, compresslevel=9) as f:
+            f.write(data)
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, **kw)
+    if r.returncode != 0:
+        raise SystemExit("command failed: %s" % " ".join(cmd))
+    return r
+
+
+def main():
+    if not os.path.exists("/root/reference"):
+        raise SystemExit("make_golden.py needs /root/reference (build container only)")
+    run(["make", "-f", os.path.join(ROOT, "oracle", "Makefile.ref"), "-j8"], stdout=subprocess.DEVNULL)
+    os.makedirs(GOLD, exist_ok=True)
+    only = set(sys.argv[1:])
+    manifest_path = os.path.join(GOLD, "manifest.json")
+    manifest = json.load(open(manifest_path)) if os.path.exists(manifest_path) else {}
+    for pe, table in ((False, FIXTURES), (True, PE_FIXTURES)):
+        for name, (gen_args, flags) in table.items():
+            if only and name not in only:
+                continue
+            with tempfile.TemporaryDirectory() as td:
+                fa = os.path.join(td, name + ".fa")
+                fasta_reads = "--fasta-reads" in gen_args
+                fq = os.path.join(td, name + (".reads.fa" if fasta_reads else ".fq"))
+                fq2 = os.path.join(td, name + "_2.fq")
+                sam = os.path.join(td, name + ".sam")
+                g = [sys.executable, GEN, "--ref-out", fa, "--reads-out", fq] + gen_args
+                if pe:
+                    g += ["--reads2-out", fq2]
+                run(g)
+                cmd = [REF_BIN, "-a", fq] + (["-b", fq2] if pe else []) + ["-d", fa] + flags + ["-p", "1", "-o", sam]
+                run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                body = b"".join(l for l in open(sam, "rb") if not l.startswith(b"@PG"))
+                gz_write(os.path.join(GOLD, name + ".fa.gz"), open(fa, "rb").read())
+                gz_write(os.path.join(GOLD, name + (".reads.fa.gz" if fasta_reads else ".fq.gz")), open(fq, "rb").read())
+                if pe:
+                    gz_write(os.path.join(GOLD, name + "_2.fq.gz"), open(fq2, "rb").read())
+                gz_write(os.path.join(GOLD, name + ".sam.gz"), body)
+                nrec = sum(1 for l in body.splitlines() if not l.startswith(b"@"))
+                manifest[name] = {"gen": gen_args, "flags": flags, "pe": pe, "records": nrec,
+                                  "reads_file": name + (".reads.fa.gz" if fasta_reads else ".fq.gz")}
+                print("%-16s %5d records  flags: %s" % (name, nrec, " ".join(flags)))
+    json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
