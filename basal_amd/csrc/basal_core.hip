@@ -1,0 +1,1022 @@
+// basal_core.hip -- the GPU core of the BASAL seed-and-extend path for MI355X (gfx950 / CDNA4).
+//
+// One read per 64-lane wavefront, persistent waves pulling reads from an atomic queue.
+// For each read a wave
+//   1. packs the read into 2-bit planes with wave ballots          (ConvertBina(r)ySeq, align.cpp:79-226)
+//   2. hashes every 3-letter seed and gathers its index count      (xseed_array + CountSeeds' index2[].n[0])
+//   3. orders the seed segments                                    (ReorderSeed/AdjustSeedStartArray, align.cpp:468-540)
+//   4. per mode, fans the candidate locations of all phases out over the lanes, 64 at a time:
+//      coalesced loads of the location list, one gather of reference words per lane,
+//      XOR/AND + popcount scoring                                  (SnpAlign/CountMismatch*, align.cpp:274-316, align.h:118-239)
+//      and the bit-parallel single-gap search                      (GapAlign/MismatchPattern*, align.cpp:348-410)
+//   5. replays the accepted candidates IN VISITATION ORDER through the sequential hit state
+//      machine (bounds, de-dup, per-level cap, threshold tightening; AddHit align.h:329-347,
+//      int2hit align.cpp:319-346), which is what makes the result bit-identical
+//   6. selects what StringAlign (align.cpp:583-612) would print.
+// All arithmetic is integer/bitwise; the kernel is bound by HBM/L2 gathers, not ALU (no MFMA).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/basal_core.h"
+#include "basal_bits.h"
+#include "basal_internal.h"
+
+using namespace basal;
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIP_TRY(x)                                                                                     \
+    do {                                                                                               \
+        hipError_t e_ = (x);                                                                           \
+        if (e_ != hipSuccess) {                                                                        \
+            g_err = std::string(#x) + ": " + hipGetErrorString(e_);                                    \
+            return BASAL_EDEVICE;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// device-side context (passed by value to the kernel)
+struct DevCtx {
+    const uint64_t *xref[2];
+    const uint32_t *ref_anchor, *contig_size, *rc_offset;
+    uint32_t ncontig;
+    const uint32_t *kmer_off, *kmer_nfwd, *locs;
+    uint32_t max_kmer_num;
+    uint32_t K, I, max_num_hits, chains, randseed, gap, gap_edge, n_mis, stream_mode, report_repeat_hits;
+    const uint8_t *tables;  // alphabet, rev_alphabet, reg_alphabet, alphabet_mread, rev_alphabet_mread
+    const uint8_t *bases;
+    const basal_read *reads;
+    uint32_t n;
+    basal_result *results;
+    basal_hit *stream;
+    unsigned long long stream_cap;
+    unsigned long long *stream_used;
+    basal_hit *scratch;  // per-wave hit log
+    uint32_t scratch_per_wave;
+    unsigned int *work_counter;
+    uint8_t carry[2][2];
+};
+
+struct SeedEnt {  // one (chain, phase) seed of the current mode
+    uint32_t off, m, nfwd, h, jj0, pre;  // pre = number of candidates before this seed in the mode's stream
+    uint32_t chain, pad;
+};
+
+template <int NWT>
+struct WaveLds {
+    static constexpr int MAXPOS = NWT * 32;
+    uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
+    uint32_t seed[2][MAXPOS];   // XT hash; bit 31: seed window contains a non-ACGT base
+    uint32_t cnt[2][MAXPOS];    // index2[seed].n[0]
+    SeedEnt ent[32];
+    uint16_t nhit[2][16];  // x_cur_n_hit[chain][level]
+    uint8_t start_arr[2][16];
+    uint8_t order[2][16];
+};
+
+// LDS written by one lane and read by the others of the SAME wave: LDS ops of a wave execute in
+// order, so only the compiler has to be told not to move or cache accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
+    return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// bit j of x -> bit 2j
+__device__ __forceinline__ uint64_t spread32(uint32_t x32) {
+    uint64_t x = x32;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x;
+}
+
+// 64 lanes each hold one 2-bit code; returns the two packed words (lanes 0-31, lanes 32-63),
+// base of lane i at bits [63-2i, 62-2i] (MSB first, as ConvertBinaySeq packs, align.cpp:88-105)
+__device__ __forceinline__ void pack_codes(uint32_t code, uint64_t &w0, uint64_t &w1) {
+    uint64_t b0 = __ballot(code & 1), b1 = __ballot(code & 2);
+    w0 = (spread32(__brev((uint32_t)b1)) << 1) | spread32(__brev((uint32_t)b0));
+    w1 = (spread32(__brev((uint32_t)(b1 >> 32))) << 1) | spread32(__brev((uint32_t)(b0 >> 32)));
+}
+
+struct ReadCtx {
+    uint32_t len, index, readset, max_snp, seq_off;
+    uint32_t nseg, ii, npos;
+    uint32_t end_element, end_offset;
+    uint32_t flag[2];
+    uint32_t n_count;
+};
+
+// ---- steps 1+2: pack, hash seeds, gather counts --------------------------------------------
+template <int NWT>
+__device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane) {
+    rc.len = rd.len;
+    rc.index = rd.index;
+    rc.readset = rd.readset;
+    rc.max_snp = rd.max_snp;
+    rc.seq_off = rd.seq_off;
+    // xflag_chain (align.cpp:83-84)
+    rc.flag[0] = (cx.chains == 1) || ((cx.chains <= 1) == (rd.readset < 2));
+    rc.flag[1] = (cx.chains == 1) || ((cx.chains <= 1) == (rd.readset == 2));
+    {  // seedseg_num (align.cpp:450)
+        int x = (int)((rc.len - cx.I + 1) / cx.K), y = (int)(rc.max_snp + 1);
+        rc.nseg = (uint32_t)(x < y ? x : y);
+    }
+    rc.ii = (rc.len - cx.I + 1) % cx.K;
+    rc.npos = rc.len >= cx.K ? rc.len - cx.K + 1 : 0;
+    rc.end_element = (rc.len - 1) / 32;                    // align.cpp:442
+    rc.end_offset = (32 - ((rc.len - 1) % 32 + 1)) << 1;   // align.cpp:443
+    const uint8_t *seq = cx.bases + rc.seq_off;
+    uint32_t nblk = (rc.len + 63) / 64;
+    uint32_t ncnt = 0;
+    for (int c = 0; c < 2; c++) {
+        if (!rc.flag[c]) continue;
+        const uint8_t *al = tab + (c ? 256 : 0), *am = tab + (c ? 1024 : 768), *rg = tab + 512;
+        for (uint32_t b = 0; b <= (uint32_t)NWT / 2; b++) {
+            uint32_t pos = b * 64 + lane;
+            uint32_t ch = 0;
+            if (b < nblk && pos < rc.len) ch = seq[c ? rc.len - 1 - pos : pos];
+            uint64_t a0, a1, v0, v1, m0, m1;
+            uint32_t valid = rg[ch];
+            pack_codes(al[ch], a0, a1);
+            pack_codes(valid, v0, v1);
+            pack_codes(am[ch], m0, m1);
+            if (c == 0) ncnt += __popcll(__ballot(b < nblk && pos < rc.len && !valid));
+            if (lane == 0) {
+                if (2 * b < (uint32_t)NWT + 1) { L.q[c][0][2 * b] = a0; L.q[c][1][2 * b] = v0; L.q[c][2][2 * b] = m0; }
+                if (2 * b + 1 < (uint32_t)NWT + 1) { L.q[c][0][2 * b + 1] = a1; L.q[c][1][2 * b + 1] = v1; L.q[c][2][2 * b + 1] = m1; }
+            }
+        }
+    }
+    if (!rc.flag[0]) {  // count N's when only chain 1 is packed (CountNs, align.cpp:40-47)
+        for (uint32_t b = 0; b < nblk; b++) {
+            uint32_t pos = b * 64 + lane;
+            uint32_t ch = pos < rc.len ? seq[pos] : 'A';
+            ncnt += __popcll(__ballot(!tab[512 + ch]));
+        }
+    }
+    rc.n_count = cx.n_mis ? ncnt : 0;
+    wave_sync();
+    // seeds: xseed_array / xseedreg_array (align.cpp:92-100) and their index counts
+    const uint32_t kbits = 2 * cx.K;
+    for (int c = 0; c < 2; c++) {
+        if (!rc.flag[c]) continue;
+        for (uint32_t p = lane; p < (uint32_t)WaveLds<NWT>::MAXPOS; p += 64) {
+            uint32_t sd = 0x80000000u, ct = 0;  // out-of-read positions: "contains N", count 0
+            if (p < rc.npos) {
+                uint32_t w = p >> 5, sh = (p & 31) * 2;
+                uint64_t a = L.q[c][0][w], b = L.q[c][1][w];
+                if (sh) {
+                    a = (a << sh) | (L.q[c][0][w + 1] >> (64 - sh));
+                    b = (b << sh) | (L.q[c][1][w + 1] >> (64 - sh));
+                }
+                uint32_t s = (uint32_t)(a >> (64 - kbits)), sb = (uint32_t)(b >> (64 - kbits));
+                uint32_t full = kbits == 32 ? 0xFFFFFFFFu : ((1u << kbits) - 1);
+                sd = XT(s);
+                ct = cx.kmer_off[sd + 1] - cx.kmer_off[sd];
+                if ((~sb) & full) sd |= 0x80000000u;
+            }
+            L.seed[c][p] = sd;
+            L.cnt[c][p] = ct;
+        }
+    }
+    wave_sync();
+}
+
+// CountSeeds (align.cpp:526-540)
+template <int NWT>
+__device__ __forceinline__ uint32_t count_seeds(const DevCtx &cx, const WaveLds<NWT> &L, int c, uint32_t n, uint32_t start) {
+    uint32_t total = 0, k = 0;
+    for (uint32_t i = 0; i < cx.I; i++) {
+        uint32_t pos = profile(n, i, cx.K, cx.I) + start - i;
+        pos = pos < (uint32_t)WaveLds<NWT>::MAXPOS ? pos : (uint32_t)WaveLds<NWT>::MAXPOS - 1;
+        uint32_t s = L.seed[c][pos];
+        if (s >> 31) k = 12;
+        total += L.cnt[c][pos] << k;
+    }
+    return total == 0 ? 9999999u : total;
+}
+
+// the global start offset (align.cpp:475-480); only meaningful when rc.ii > 0
+template <int NWT>
+__device__ uint32_t best_start_offset(const DevCtx &cx, const WaveLds<NWT> &L, const ReadCtx &rc, int c, int lane, uint32_t inherited) {
+    uint32_t best = 0xffffffffu, so = inherited;
+    for (uint32_t st = 0; st < rc.ii; st++) {
+        uint32_t cs = (uint32_t)lane < rc.nseg ? count_seeds(cx, L, c, (uint32_t)lane, st) : 0;
+        uint32_t tt = wave_sum(cs);
+        if (tt < best) { best = tt; so = st; }
+    }
+    return so;
+}
+
+// ---- step 3: ReorderSeed ------------------------------------------------------------------
+template <int NWT>
+__device__ void reorder_seed(const DevCtx &cx, WaveLds<NWT> &L, const ReadCtx &rc, int lane, const uint32_t so[2]) {
+    uint32_t max_offset = rc.ii;
+    for (int c = 0; c < 2; c++) {
+        if (!rc.flag[c]) continue;
+        if ((uint32_t)lane < 16) L.start_arr[c][lane] = (uint8_t)so[c];
+        wave_sync();
+        // AdjustSeedStartArray (align.cpp:500-524)
+        for (uint32_t i = 0; i < rc.nseg; i++) {
+            uint32_t ptr = (i % 2 == 0) ? i / 2 : rc.nseg - 1 - i / 2;
+            uint32_t start = (ptr == 0) ? 0 : L.start_arr[c][ptr - 1];
+            uint32_t end = (ptr == rc.nseg - 1) ? max_offset : L.start_arr[c][ptr + 1];
+            uint32_t cand = start + lane;
+            bool valid = cand <= end && lane < 16;
+            uint32_t tt = valid ? count_seeds(cx, L, c, ptr, cand) : 0xffffffffu;
+            uint32_t m = wave_min(tt);
+            uint32_t pick = start;
+            if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)__ballot(valid && tt == m)) - 1;
+            if (lane == 0) L.start_arr[c][ptr] = (uint8_t)pick;
+            wave_sync();
+        }
+        // weights + sort ascending by (int weight, segment) (align.cpp:492-495)
+        int32_t w = 0x7fffffff;
+        if ((uint32_t)lane < rc.nseg) w = (int32_t)count_seeds(cx, L, c, (uint32_t)lane, L.start_arr[c][lane]);
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < rc.nseg; j++) {
+            int32_t wj = (int32_t)rdlane((uint32_t)w, (int)j);
+            rank += (wj < w) || (wj == w && j < (uint32_t)lane);
+        }
+        if ((uint32_t)lane < rc.nseg) L.order[c][rank] = (uint8_t)lane;
+    }
+    wave_sync();
+}
+
+// ---- candidate scoring ----------------------------------------------------------------------
+// CountMismatch / CountMismatch_new (align.h:118-131, 199-239). Returns the exact mismatch count if
+// it is <= thr, otherwise some value > thr (early exit in word order).
+template <int NWT, bool NEWRULE>
+__device__ __forceinline__ uint32_t count_mismatch(const uint64_t *__restrict__ s, const uint64_t (*q)[NWT + 1], uint32_t off2, uint32_t nw,
+                                                   uint32_t thr, uint32_t ncount) {
+    uint64_t s0 = s[0], s1 = s[1];  // one gather covers the common case (early exit in word 0/1)
+    uint32_t mm = ncount;
+    {
+        uint64_t rw = q[0][0] >> off2, mw = q[1][0] >> off2, cw = NEWRULE ? q[2][0] >> off2 : 0;
+        mm += XM64(cmp_word<NEWRULE>(rw, cw, s0) & mw);
+        if (mm > thr || nw <= 1) return mm;
+    }
+#pragma unroll 1
+    for (uint32_t i = 1; i < nw; i++) {
+        uint64_t si = i == 1 ? s1 : s[i];
+        uint64_t rw = ((q[0][i - 1] << 1) << (63 - off2)) | (q[0][i] >> off2);
+        uint64_t mw = ((q[1][i - 1] << 1) << (63 - off2)) | (q[1][i] >> off2);
+        uint64_t cw = NEWRULE ? ((q[2][i - 1] << 1) << (63 - off2)) | (q[2][i] >> off2) : 0;
+        mm += XM64(cmp_word<NEWRULE>(rw, cw, si) & mw);
+        if (mm > thr) return mm;
+    }
+    return mm;
+}
+
+// mismatch bitmap of the whole read against the reference starting at `loc` (reference shifted
+// into the read frame, no N mask): the word loop of MismatchPattern0/1 (align.h:140-165, 179-193).
+template <int NWT, bool NEWRULE>
+__device__ __forceinline__ void mismatch_map(const uint64_t *__restrict__ xs, uint32_t loc, const uint64_t (*q)[NWT + 1], uint32_t end_element,
+                                             uint32_t end_offset, uint64_t D[NWT]) {
+    const uint64_t *s = xs + (loc >> 5);
+    uint32_t off2 = (loc & 31) * 2;
+    uint64_t cur = s[0];
+#pragma unroll
+    for (int i = 0; i < NWT; i++) {
+        uint64_t d = 0;
+        if ((uint32_t)i <= end_element) {
+            uint64_t nxt = s[i + 1];
+            uint64_t tmp = (cur << off2) | ((nxt >> (63 - off2)) >> 1);
+            cur = nxt;
+            if (!NEWRULE) tmp ^= q[0][i] & XC64(tmp);
+            else {
+                uint64_t M2 = XC64(tmp) | q[2][i];
+                uint64_t M3 = M2_judge(M2);
+                tmp ^= ((~M3) & M2) | (M3 & q[0][i]);
+            }
+            if ((uint32_t)i == end_element) tmp = (tmp >> end_offset) << end_offset;
+            d = pair_mask(tmp);
+        }
+        D[i] = d;
+    }
+}
+
+// GapAlign (align.cpp:348-410) for one candidate, bit-parallel: instead of the reference's
+// position arrays mm_index[][] it keeps the mismatch bitmaps and answers "i-th mismatch from the
+// left" / "first mismatch at distance >= X from the right" with popcounts. Same decisions.
+template <int NWT, bool NEWRULE>
+__device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uint32_t loc, const uint64_t (*q)[NWT + 1], const ReadCtx &rc, uint32_t thr,
+                          uint32_t seed_pos, uint32_t &gap_snp, uint32_t &gap_pos_out, int &shift_out) {
+    if (thr < 2) return false;
+    uint64_t D0[NWT];
+    mismatch_map<NWT, NEWRULE>(xs, loc, q, rc.end_element, rc.end_offset, D0);
+    const int len = (int)rc.len;
+    // MismatchPattern0 returns the position of mismatch #(thr-1) (or len); GapAlign gives up if
+    // that lies before the end of the seed (align.cpp:365): >= thr-1 mismatches in [0, seed end)
+    {
+        int lim = (int)(seed_pos + cx.K);
+        uint32_t c0 = 0;
+#pragma unroll
+        for (int w = 0; w < NWT; w++) c0 += popc64(D0[w] & prefix_pairs(lim - 32 * w));
+        if (c0 >= thr - 1) return false;
+    }
+    for (uint32_t tt = 1; tt <= cx.gap * 2; tt++) {
+        uint32_t t = (tt + 1) / 2;
+        int shift = (tt & 1) ? -(int)t : (int)t;
+        int shift1 = shift < 0 ? shift : 0;
+        if (thr < 1 + t) break;
+        uint64_t D1[NWT];
+        mismatch_map<NWT, NEWRULE>(xs, loc + (uint32_t)shift, q, rc.end_element, rc.end_offset, D1);
+        int rl = len - (int)t - 1;
+        uint32_t i = 0;  // index of the current left-side mismatch (mmi1[i])
+#pragma unroll
+        for (int w = 0; w < NWT; w++) {
+            uint64_t bits = D0[w];
+            while (bits && i < thr - t) {
+                int b = __clzll((long long)bits) >> 1;
+                bits &= ~(1ULL << (62 - 2 * b));
+                int gp = w * 32 + b;
+                if (gp >= (int)cx.gap_edge && gp < rl) {
+                    int X = len + shift1 - gp;
+                    if (X < (int)cx.gap_edge) X = (int)cx.gap_edge;
+                    int pcut = len - X;  // right-side mismatches at positions >= pcut are at distance < X
+                    uint32_t jstar = 0;
+                    int plast = -1;      // highest mismatch position < pcut
+#pragma unroll
+                    for (int v = 0; v < NWT; v++) {
+                        uint64_t pre = prefix_pairs(pcut - 32 * v);
+                        jstar += popc64(D1[v] & ~pre);
+                        uint64_t lo = D1[v] & pre;
+                        if (lo) plast = v * 32 + 31 - (__ffsll((unsigned long long)lo) - 1) / 2;
+                    }
+                    if (plast >= 0 && jstar < thr - t - i) {
+                        int m2 = len - 1 - plast;
+                        if (m2 < rl) {  // m2 >= X >= gap_edge by construction
+                            gap_snp = i + jstar + t;
+                            int clip = gp + (int)cx.gap_edge - len - shift1;
+                            if (clip > 0) gp -= clip;
+                            gap_pos_out = (uint32_t)gp;
+                            shift_out = shift;
+                            return true;
+                        }
+                    }
+                }
+                i++;
+            }
+        }
+    }
+    return false;
+}
+
+// ---- the sequential hit state of one read (wave-uniform) ----------------------------------
+struct HitState {
+    uint32_t thr;     // snp_thres
+    uint32_t nlog;    // records in the log
+    uint64_t key0, key1;  // per lane: de-dup keys of log records lane and lane+64
+};
+
+__device__ __forceinline__ uint64_t hit_key(uint32_t contig, uint32_t loc, bool gapped) {
+    return ((uint64_t)contig << 33) | ((uint64_t)gapped << 32) | loc;
+}
+
+// int2hit + AddHit (align.cpp:319-346, align.h:329-347). All arguments wave-uniform.
+// returns 1 when SnpAlign must stop (level-0 cap), else 0; may lower st.thr.
+template <int NWT>
+__device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t loc, uint32_t strand,
+                            uint32_t chain, uint32_t w, uint32_t mode, int gap_size, uint32_t gap_pos, int lane) {
+    uint32_t left = 0, right = cx.ncontig;
+    while (left < right - 1) {
+        uint32_t mid = (left + right) / 2;
+        if (loc >= cx.ref_anchor[mid]) left = mid;
+        else right = mid;
+    }
+    uint32_t chr = (left * 2 + strand) & 0x3FFFF;
+    uint32_t l = loc - cx.ref_anchor[left];
+    uint32_t gp = gap_pos & 0x1FF;
+    if (strand) {
+        l = cx.rc_offset[chr >> 1] - rc.len - l;
+        gp = (uint32_t)((int)rc.len + (gap_size < 0 ? gap_size : 0) - (int)gp) & 0x1FF;
+        l -= (uint32_t)gap_size;
+    }
+    if ((int)l < 0) return 0;
+    if (l + rc.len > cx.contig_size[chr >> 1]) return 0;
+    uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
+    bool dup = ((uint32_t)lane < st.nlog && st.key0 == key) || ((uint32_t)lane + 64 < st.nlog && st.key1 == key);
+    if (__ballot(dup)) return 0;
+    for (uint32_t base = 128; base < st.nlog; base += 64) {  // long logs: scan the spilled part
+        bool d = false;
+        if (base + lane < st.nlog) {
+            basal_hit h = log[base + lane];
+            d = hit_key(h.chr >> 1, h.loc, h.gap_size != 0) == key;
+        }
+        if (__ballot(d)) return 0;
+    }
+    uint32_t n = st.nlog;
+    if (n < cx.scratch_per_wave) {
+        if (lane == 0) {
+            basal_hit h;
+            h.loc = l; h.chr = chr; h.gap_size = (int8_t)gap_size; h.strand = (uint8_t)(((strand << 1) | chain) & 3);
+            h.gap_pos = (uint16_t)gp; h.level = (uint8_t)w; h.chain = (uint8_t)chain; h.mode = (uint8_t)mode; h.pad = 0;
+            log[n] = h;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
+        if ((uint32_t)lane == n) st.key0 = key;
+        if ((uint32_t)lane + 64 == n) st.key1 = key;
+        st.nlog = n + 1;
+    }
+    uint32_t tot;
+    {
+        uint32_t a = L.nhit[chain][w] + 1u;
+        if (lane == 0) L.nhit[chain][w] = (uint16_t)a;
+        tot = a + L.nhit[chain ^ 1][w];
+    }
+    wave_sync();
+    if (tot >= cx.max_num_hits) {
+        if (w == 0) return 1;
+        st.thr = w - 1;
+    }
+    return 0;
+}
+
+// k-th (0-based) log record with the given level and chain, in insertion order
+__device__ uint32_t find_kth(const basal_hit *log, uint32_t nlog, uint32_t level, uint32_t chain, uint32_t k, int lane) {
+    for (uint32_t base = 0; base < nlog; base += 64) {
+        bool m = false;
+        if (base + lane < nlog) {
+            const basal_hit &h = log[base + lane];
+            m = h.level == level && h.chain == chain;
+        }
+        uint64_t b = __ballot(m);
+        uint32_t c = (uint32_t)__popcll(b);
+        if (k < c) {
+            for (uint32_t i = 0; i < k; i++) b &= b - 1;
+            return base + (uint32_t)__ffsll((unsigned long long)b) - 1;
+        }
+        k -= c;
+    }
+    return 0xffffffffu;
+}
+
+// ---- one read ----------------------------------------------------------------------------------
+template <int NWT, bool NEWRULE, bool GAP>
+__device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab, basal_hit *log, uint32_t r, int lane) {
+    basal_read rd = cx.reads[r];
+    basal_result res;
+    memset(&res, 0, sizeof(res));
+    res.best_level = 0xFF;
+    if (rd.len == 0 || rd.len > (uint32_t)NWT * 32 || rd.len > BASAL_MAXREADLEN) {
+        res.status = BASAL_READ_SKIPPED;
+        if (lane == 0) cx.results[r] = res;
+        return;
+    }
+    ReadCtx rc;
+    uint32_t so[2];
+    uint32_t slot = rd.readset == 2 ? 1 : 0;
+    so[0] = cx.carry[slot][0];
+    so[1] = cx.carry[slot][1];
+    if (rd.stale_src < cx.n) {  // inherit xseed_start_offset from an earlier read of this batch (align.cpp:475-480)
+        basal_read src = cx.reads[rd.stale_src];
+        prep_read<NWT>(cx, L, tab, src, rc, lane);
+        for (int c = 0; c < 2; c++)
+            if (rc.flag[c]) so[c] = best_start_offset<NWT>(cx, L, rc, c, lane, so[c]);
+    }
+    prep_read<NWT>(cx, L, tab, rd, rc, lane);
+    for (int c = 0; c < 2; c++)
+        if (rc.flag[c] && rc.ii > 0) so[c] = best_start_offset<NWT>(cx, L, rc, c, lane, so[c]);
+    res.start_off[0] = (uint8_t)so[0];
+    res.start_off[1] = (uint8_t)so[1];
+    if (lane < 32) L.nhit[lane >> 4][lane & 15] = 0;
+    wave_sync();
+    reorder_seed<NWT>(cx, L, rc, lane, so);
+
+    HitState st;
+    st.thr = rc.max_snp;
+    st.nlog = 0;
+    st.key0 = st.key1 = ~0ULL;
+    const uint32_t rnd = myrand(rc.index, cx.randseed);
+    const uint32_t nent = 2 * cx.I;
+
+    bool done = false;
+    for (uint32_t mode = 0; mode < rc.nseg && !done; mode++) {
+        // the seeds of this mode, chain-major then phase (the order SnpAlign visits them, align.cpp:275-279)
+        uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0;
+        if ((uint32_t)lane < nent) {
+            uint32_t c = (uint32_t)lane / cx.I, i = (uint32_t)lane % cx.I;
+            if (rc.flag[c]) {
+                uint32_t seg = L.order[c][mode];
+                uint32_t pos = profile(seg, i, cx.K, cx.I) + L.start_arr[c][seg] - i;
+                uint32_t sd = L.seed[c][pos] & 0x7fffffffu, m = L.cnt[c][pos];
+                if (m != 0 && m <= cx.max_kmer_num && pos < rc.npos) {
+                    e_m = m;
+                    e_off = cx.kmer_off[sd];
+                    e_nfwd = cx.kmer_nfwd[sd];
+                    e_h = pos;
+                    e_jj0 = rnd % m;
+                    e_chain = c;
+                }
+            }
+        }
+        uint32_t inc = e_m;  // inclusive prefix sum over lanes 0..nent-1
+        for (int o = 1; o < 32; o <<= 1) {
+            uint32_t v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if ((uint32_t)lane < nent) {
+            SeedEnt e = {e_off, e_m, e_nfwd, e_h, e_jj0, inc - e_m, e_chain, 0};
+            L.ent[lane] = e;
+        }
+        wave_sync();
+        const uint32_t T = rdlane(inc, (int)nent - 1);
+
+        for (uint32_t t0 = 0; t0 < T && !done; t0 += 64) {
+            uint32_t t = t0 + lane;
+            bool active = t < T;
+            uint32_t ei = 0;
+            for (uint32_t e = 0; e + 1 < nent; e++) ei += (t >= rdlane(inc, (int)e));
+            SeedEnt e = L.ent[active ? ei : 0];
+            uint32_t loc = 0, strand = 0, mm = 0xffff;
+            const uint64_t(*q)[NWT + 1] = L.q[e.chain];
+            if (active) {
+                uint32_t jj = e.jj0 + (t - e.pre);
+                if (jj >= e.m) jj -= e.m;
+                loc = cx.locs[e.off + jj] - e.h;
+                strand = jj >= e.nfwd;
+                uint32_t off2 = (loc & 31) * 2;
+                uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
+                mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
+            }
+            uint64_t act = __ballot(active);
+            uint64_t ung_pending = act, gap_pending = GAP ? act : 0;
+            bool gfound = false;
+            uint32_t gsnp = 0, gpos = 0;
+            int gshift = 0;
+            for (;;) {
+                if (GAP) {
+                    bool mine = (gap_pending >> lane) & 1;
+                    gfound = false;
+                    if (mine) gfound = gap_align<NWT, NEWRULE>(cx, cx.xref[strand], loc, q, rc, st.thr, e.h, gsnp, gpos, gshift);
+                }
+                uint64_t acc = __ballot(active && mm <= st.thr) & ung_pending;
+                uint64_t gm = GAP ? (__ballot(gfound) & gap_pending) : 0;
+                bool recompute = false;
+                while (acc | gm) {
+                    int l = __ffsll((unsigned long long)(acc | gm)) - 1;
+                    uint64_t bit = 1ULL << l;
+                    uint32_t thr_before = st.thr;
+                    uint32_t lloc = rdlane(loc, l), lstrand = rdlane(strand, l), lchain = rdlane(e.chain, l);
+                    if (acc & bit) {
+                        acc &= ~bit;
+                        ung_pending &= ~bit;
+                        uint32_t lmm = rdlane(mm, l);
+                        if (add_hit<NWT>(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane)) { done = true; break; }
+                        if (st.thr != thr_before) {
+                            acc = __ballot(active && mm <= st.thr) & acc;
+                            if (GAP) { gap_pending &= ~(bit - 1); recompute = true; break; }
+                        }
+                    }
+                    if (gm & bit) {
+                        gm &= ~bit;
+                        gap_pending &= ~bit;
+                        uint32_t lsnp = rdlane(gsnp, l), lgp = rdlane(gpos, l);
+                        int lsh = (int)rdlane((uint32_t)gshift, l);
+                        thr_before = st.thr;
+                        if (add_hit<NWT>(cx, L, st, log, rc, lloc, lstrand, lchain, lsnp, mode, lsh, lgp, lane)) { done = true; break; }
+                        if (st.thr != thr_before) {
+                            acc = __ballot(active && mm <= st.thr) & acc;
+                            gap_pending &= ~((bit << 1) - 1);
+                            recompute = true;
+                            break;
+                        }
+                    }
+                }
+                if (!recompute || done) break;
+            }
+        }
+        // RunAlign: stop once any level <= mode holds a hit (align.cpp:462); `done` = AddHit said stop
+        uint32_t any = 0;
+        if ((uint32_t)lane <= mode && lane < 16) any = L.nhit[0][lane] | L.nhit[1][lane];
+        if (__ballot(any != 0)) done = true;
+    }
+
+    // ---- StringAlign's choice (align.cpp:583-612) ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t tot = 0;
+    if (lane < 16 && (uint32_t)lane <= rc.max_snp) tot = (uint32_t)L.nhit[0][lane] + L.nhit[1][lane];
+    uint64_t nz = __ballot(tot != 0);
+    if (nz) {
+        uint32_t ii = (uint32_t)__ffsll((unsigned long long)nz) - 1;
+        uint32_t nh = L.nhit[0][ii], nc = L.nhit[1][ii], sum = nh + nc;
+        res.best_level = (uint8_t)ii;
+        res.n_hit = (uint16_t)nh;
+        res.n_chit = (uint16_t)nc;
+        uint32_t j = sum == 1 ? 0 : rnd % sum;
+        uint32_t idx = j < nh ? find_kth(log, st.nlog, ii, 0, j, lane) : find_kth(log, st.nlog, ii, 1, j - nh, lane);
+        if (idx != 0xffffffffu) res.best = log[idx];
+        if (cx.stream_mode == BASAL_STREAM_BEST || cx.stream_mode == BASAL_STREAM_ALL) {
+            uint32_t need = cx.stream_mode == BASAL_STREAM_ALL ? st.nlog : sum;
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(cx.stream_used, (unsigned long long)need);
+            first = ((unsigned long long)rfl((uint32_t)(first >> 32)) << 32) | rfl((uint32_t)first);
+            res.stream_first = (uint32_t)first;
+            res.stream_n = need;
+            if (first + need > cx.stream_cap) res.status = BASAL_READ_OVERFLOW;
+            else if (cx.stream_mode == BASAL_STREAM_ALL) {
+                for (uint32_t i = lane; i < st.nlog; i += 64) cx.stream[first + i] = log[i];
+            } else {
+                uint32_t outp = 0;
+                for (uint32_t c = 0; c < 2; c++)
+                    for (uint32_t base = 0; base < st.nlog; base += 64) {
+                        bool m = false;
+                        basal_hit h;
+                        if (base + lane < st.nlog) {
+                            h = log[base + lane];
+                            m = h.level == ii && h.chain == c;
+                        }
+                        uint64_t b = __ballot(m);
+                        if (m) cx.stream[first + outp + (uint32_t)__popcll(b & ((1ULL << lane) - 1))] = h;
+                        outp += (uint32_t)__popcll(b);
+                    }
+            }
+        }
+    } else if (cx.stream_mode == BASAL_STREAM_ALL && st.nlog) {
+        // hits exist only above read_max_snp_num: cannot happen (levels are <= thr <= max_snp); kept for safety
+        res.stream_n = 0;
+    }
+    if (lane == 0) cx.results[r] = res;
+}
+
+template <int NWT, bool NEWRULE, bool GAP>
+__global__ __launch_bounds__(256) void align_kernel(DevCtx cx) {
+    __shared__ uint8_t s_tab[5 * 256];
+    __shared__ WaveLds<NWT> s_w[4];
+    for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    WaveLds<NWT> &L = s_w[wv];
+    if (lane <= NWT) {  // zero the pad words once
+        for (int c = 0; c < 2; c++)
+            for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
+    }
+    wave_sync();
+    basal_hit *log = cx.scratch + (size_t)(blockIdx.x * 4 + wv) * cx.scratch_per_wave;
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(cx.work_counter, 1u);
+        r = rfl(r);
+        if (r >= cx.n) break;
+        process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, lane);
+    }
+}
+
+typedef void (*kernel_fn)(DevCtx);
+template <int NWT>
+kernel_fn pick_kernel(bool newrule, bool gap) {
+    if (newrule) return gap ? align_kernel<NWT, true, true> : align_kernel<NWT, true, false>;
+    return gap ? align_kernel<NWT, false, true> : align_kernel<NWT, false, false>;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side of the core
+struct basal_core {
+    basal_params p;
+    int device = 0;
+    hipDeviceProp_t prop;
+    // reference + index in HBM
+    uint64_t *d_xref[2] = {nullptr, nullptr};
+    uint64_t nwords = 0;
+    uint32_t *d_anchor = nullptr, *d_size = nullptr, *d_rcoff = nullptr;
+    uint32_t ncontig = 0;
+    uint32_t *d_koff = nullptr, *d_knfwd = nullptr, *d_locs = nullptr;
+    uint64_t nlocs = 0;
+    uint32_t total_kmers = 0, max_kmer_num = 0;
+    bool have_ref = false, have_index = false;
+    uint8_t *d_tables = nullptr;
+    // work buffers
+    basal_hit *d_scratch = nullptr;
+    uint32_t scratch_per_wave = 0;
+    unsigned int *d_counter = nullptr;
+    uint32_t grid = 0;
+    int nwt = 0;
+    // staging for the host-buffer entry point
+    uint8_t *d_bases = nullptr; size_t cap_bases = 0;
+    basal_read *d_reads = nullptr; size_t cap_reads = 0;
+    basal_result *d_results = nullptr;
+    basal_hit *d_stream = nullptr; size_t cap_stream = 0;
+    unsigned long long *d_used = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false, timed = false;
+};
+
+extern "C" const char *basal_last_error(void) { return g_err.c_str(); }
+namespace basal { void set_error(const std::string &s) { g_err = s; } }
+
+static uint32_t pow3(uint32_t k) {
+    uint32_t t = 1;
+    for (uint32_t i = 0; i < k; i++) t *= 3;
+    return t;
+}
+
+extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t **out) {
+    if (!p || !out) { g_err = "null argument"; return BASAL_EINVAL; }
+    if (p->seed_size < 10 || p->seed_size > 16 || p->index_interval < 1 || p->index_interval > 16 || p->gap > BASAL_MAXGAPS ||
+        p->max_num_hits < 1 || p->max_num_hits > BASAL_MAXHITS || p->chains > 2) {
+        g_err = "parameter out of range (seed_size 10..16, index_interval 1..16, gap<=3, 1<=max_num_hits<=1000, chains 0..2)";
+        return BASAL_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device: the BASAL core needs an MI355X (gfx950); there is no CPU fallback"; return BASAL_EDEVICE; }
+    if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return BASAL_EINVAL; }
+    basal_core *c = new basal_core();
+    c->p = *p;
+    c->device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipGetDeviceProperties(&c->prop, device));
+    HIP_TRY(hipMalloc(&c->d_tables, 5 * 256));
+    uint8_t tabs[5 * 256];
+    memcpy(tabs, p->alphabet, 256);
+    memcpy(tabs + 256, p->rev_alphabet, 256);
+    memcpy(tabs + 512, p->reg_alphabet, 256);
+    memcpy(tabs + 768, p->alphabet_mread, 256);
+    memcpy(tabs + 1024, p->rev_alphabet_mread, 256);
+    HIP_TRY(hipMemcpy(c->d_tables, tabs, sizeof tabs, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&c->d_counter, sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&c->d_used, sizeof(unsigned long long)));
+    HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    c->total_kmers = pow3(p->seed_size);
+    c->scratch_per_wave = 16 * p->max_num_hits;
+    *out = c;
+    return BASAL_OK;
+}
+
+extern "C" void basal_core_destroy(basal_core_t *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
+    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_tables); hipFree(c->d_scratch);
+    hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int basal_core_set_reference(basal_core_t *c, const uint64_t *xref_fwd, const uint64_t *xref_rc, uint64_t nwords, const uint32_t *ref_anchor,
+                                        const uint32_t *contig_size, const uint32_t *rc_offset, uint32_t ncontig) {
+    if (!c || !xref_fwd || !xref_rc || !ref_anchor || !contig_size || !rc_offset || ncontig == 0 || nwords < 2 * BASAL_REF_MARGIN) {
+        g_err = "set_reference: bad argument";
+        return BASAL_EINVAL;
+    }
+    if ((uint64_t)ref_anchor[ncontig] != (nwords - BASAL_REF_MARGIN) * 32) {
+        g_err = "set_reference: ref_anchor[ncontig] does not match nwords (layout: 400 margin words, contigs, 400 margin words)";
+        return BASAL_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
+    c->d_xref[0] = c->d_xref[1] = nullptr; c->d_anchor = c->d_size = c->d_rcoff = nullptr;
+    // 64 extra words so a lane may always fetch one word beyond the alignment
+    for (int s = 0; s < 2; s++) {
+        HIP_TRY(hipMalloc(&c->d_xref[s], (nwords + 64) * 8));
+        HIP_TRY(hipMemset(c->d_xref[s], 0, (nwords + 64) * 8));
+        HIP_TRY(hipMemcpy(c->d_xref[s], s ? xref_rc : xref_fwd, nwords * 8, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&c->d_anchor, (ncontig + 1) * 4));
+    HIP_TRY(hipMalloc(&c->d_size, ncontig * 4));
+    HIP_TRY(hipMalloc(&c->d_rcoff, ncontig * 4));
+    HIP_TRY(hipMemcpy(c->d_anchor, ref_anchor, (ncontig + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_size, contig_size, ncontig * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_rcoff, rc_offset, ncontig * 4, hipMemcpyHostToDevice));
+    c->nwords = nwords;
+    c->ncontig = ncontig;
+    c->have_ref = true;
+    return BASAL_OK;
+}
+
+extern "C" int basal_core_set_index(basal_core_t *c, const uint32_t *kmer_off, const uint32_t *kmer_nfwd, const uint32_t *locs, uint64_t nlocs,
+                                    uint32_t max_kmer_num) {
+    if (!c || !kmer_off || !kmer_nfwd || (!locs && nlocs)) { g_err = "set_index: bad argument"; return BASAL_EINVAL; }
+    if (nlocs >= 0xFFFFFFFFull) { g_err = "set_index: more than 2^32-1 index entries (the reference's 32-bit counters overflow too)"; return BASAL_EINVAL; }
+    if (kmer_off[c->total_kmers] != (uint32_t)nlocs) { g_err = "set_index: kmer_off[3^k] != nlocs"; return BASAL_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs);
+    c->d_koff = c->d_knfwd = c->d_locs = nullptr;
+    HIP_TRY(hipMalloc(&c->d_koff, ((size_t)c->total_kmers + 1) * 4));
+    HIP_TRY(hipMalloc(&c->d_knfwd, (size_t)c->total_kmers * 4));
+    HIP_TRY(hipMalloc(&c->d_locs, (nlocs + 64) * 4));
+    HIP_TRY(hipMemcpy(c->d_koff, kmer_off, ((size_t)c->total_kmers + 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_knfwd, kmer_nfwd, (size_t)c->total_kmers * 4, hipMemcpyHostToDevice));
+    if (nlocs) HIP_TRY(hipMemcpy(c->d_locs, locs, nlocs * 4, hipMemcpyHostToDevice));
+    c->nlocs = nlocs;
+    c->max_kmer_num = max_kmer_num;
+    c->have_index = true;
+    return BASAL_OK;
+}
+
+extern "C" int basal_core_get_index(basal_core_t *c, uint32_t *kmer_off, uint32_t *kmer_nfwd, uint32_t *locs, uint64_t *nlocs, uint32_t *max_kmer_num) {
+    if (!c || !c->have_index) { g_err = "get_index: no index"; return BASAL_ESTATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (kmer_off) HIP_TRY(hipMemcpy(kmer_off, c->d_koff, ((size_t)c->total_kmers + 1) * 4, hipMemcpyDeviceToHost));
+    if (kmer_nfwd) HIP_TRY(hipMemcpy(kmer_nfwd, c->d_knfwd, (size_t)c->total_kmers * 4, hipMemcpyDeviceToHost));
+    if (locs && c->nlocs) HIP_TRY(hipMemcpy(locs, c->d_locs, c->nlocs * 4, hipMemcpyDeviceToHost));
+    if (nlocs) *nlocs = c->nlocs;
+    if (max_kmer_num) *max_kmer_num = c->max_kmer_num;
+    return BASAL_OK;
+}
+
+extern "C" int basal_core_set_timing(basal_core_t *c, int on) {
+    if (!c) return BASAL_EINVAL;
+    c->timing = on != 0;
+    return BASAL_OK;
+}
+
+extern "C" float basal_core_last_kernel_ms(basal_core_t *c) {
+    if (!c || !c->timed) return 0.f;
+    float ms = 0.f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return 0.f;
+    return ms;
+}
+
+static int ensure_launch_geometry(basal_core *c) {
+    if (c->grid) return BASAL_OK;
+    uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
+    const char *env = getenv("BASAL_BLOCKS_PER_CU");
+    uint32_t per_cu = env ? (uint32_t)atoi(env) : 4;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    c->grid = cus * per_cu;
+    HIP_TRY(hipMalloc(&c->d_scratch, (size_t)c->grid * 4 * c->scratch_per_wave * sizeof(basal_hit)));
+    return BASAL_OK;
+}
+
+extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_t *threads, uint32_t *lds_bytes) {
+    if (!c) return BASAL_EINVAL;
+    int rc = ensure_launch_geometry(c);
+    if (rc) return rc;
+    if (blocks) *blocks = c->grid;
+    if (threads) *threads = 256;
+    if (lds_bytes) *lds_bytes = c->nwt == 16 ? (uint32_t)(4 * sizeof(WaveLds<16>) + 1280) : c->nwt == 8 ? (uint32_t)(4 * sizeof(WaveLds<8>) + 1280) : (uint32_t)(4 * sizeof(WaveLds<4>) + 1280);
+    return BASAL_OK;
+}
+
+// max_len: the longest read of the batch, selects the kernel instantiation
+static int launch_align(basal_core *c, const void *d_bases, const void *d_reads, uint32_t n, uint32_t max_len, int stream_mode, void *d_results,
+                        void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2], hipStream_t s) {
+    if (!c->have_ref || !c->have_index) { g_err = "align: reference/index not staged (call set_reference and set_index/build_index first)"; return BASAL_ESTATE; }
+    if (stream_mode < 0 || stream_mode > 2) { g_err = "align: bad stream_mode"; return BASAL_EINVAL; }
+    if (stream_mode != BASAL_STREAM_NONE && (!d_stream || !d_stream_used)) { g_err = "align: stream buffers required for this stream_mode"; return BASAL_EINVAL; }
+    int rc = ensure_launch_geometry(c);
+    if (rc) return rc;
+    if (n == 0) return BASAL_OK;
+    DevCtx cx;
+    memset(&cx, 0, sizeof cx);
+    cx.xref[0] = c->d_xref[0]; cx.xref[1] = c->d_xref[1];
+    cx.ref_anchor = c->d_anchor; cx.contig_size = c->d_size; cx.rc_offset = c->d_rcoff; cx.ncontig = c->ncontig;
+    cx.kmer_off = c->d_koff; cx.kmer_nfwd = c->d_knfwd; cx.locs = c->d_locs; cx.max_kmer_num = c->max_kmer_num;
+    cx.K = c->p.seed_size; cx.I = c->p.index_interval; cx.max_num_hits = c->p.max_num_hits; cx.chains = c->p.chains;
+    cx.randseed = c->p.randseed; cx.gap = c->p.gap; cx.gap_edge = c->p.gap_edge; cx.n_mis = c->p.n_mis;
+    cx.stream_mode = (uint32_t)stream_mode; cx.report_repeat_hits = c->p.report_repeat_hits;
+    cx.tables = c->d_tables; cx.bases = (const uint8_t *)d_bases; cx.reads = (const basal_read *)d_reads; cx.n = n;
+    cx.results = (basal_result *)d_results; cx.stream = (basal_hit *)d_stream; cx.stream_cap = stream_cap;
+    cx.stream_used = (unsigned long long *)d_stream_used;
+    cx.scratch = c->d_scratch; cx.scratch_per_wave = c->scratch_per_wave; cx.work_counter = c->d_counter;
+    memcpy(cx.carry, carry, 4);
+    int nwt = max_len <= 128 ? 4 : max_len <= 256 ? 8 : 16;
+    c->nwt = nwt;
+    bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
+    kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp) : nwt == 8 ? pick_kernel<8>(nr, gp) : pick_kernel<16>(nr, gp);
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned int), s));
+    uint32_t grid = c->grid;
+    uint32_t need = (n + 3) / 4;
+    if (grid > need) grid = need;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, cx);
+    HIP_TRY(hipGetLastError());
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, s)); c->timed = true; }
+    return BASAL_OK;
+}
+
+extern "C" int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const void *d_reads, uint32_t n, int stream_mode, void *d_results,
+                                             void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2], uint32_t max_len,
+                                             void *hip_stream) {
+    if (!c || (n && (!d_bases || !d_reads || !d_results))) { g_err = "align_batch_device: null argument"; return BASAL_EINVAL; }
+    if (max_len == 0 || max_len > BASAL_MAXREADLEN) { g_err = "align_batch_device: max_len must be 1..480"; return BASAL_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
+    return launch_align(c, d_bases, d_reads, n, max_len, stream_mode, d_results, d_stream, stream_cap, d_stream_used, carry ? carry : zero_carry,
+                        (hipStream_t)hip_stream);
+}
+
+template <typename T>
+static int grow(T *&p, size_t &cap, size_t need) {
+    if (need <= cap) return BASAL_OK;
+    hipFree(p);
+    p = nullptr;
+    size_t nc = need + need / 4 + 1024;
+    HIP_TRY(hipMalloc(&p, nc * sizeof(T)));
+    cap = nc;
+    return BASAL_OK;
+}
+
+extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, int stream_mode,
+                                      basal_result *results, basal_hit *stream, uint64_t stream_cap, uint64_t *stream_used, uint8_t carry[2][2]) {
+    if (!c || (n && (!bases || !reads || !results))) { g_err = "align_batch: null argument"; return BASAL_EINVAL; }
+    if (stream_mode != BASAL_STREAM_NONE && (!stream || !stream_used)) { g_err = "align_batch: stream buffers required for this stream_mode"; return BASAL_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (stream_used) *stream_used = 0;
+    if (n == 0) return BASAL_OK;
+    uint32_t max_len = 0;
+    const uint32_t K = c->p.seed_size, I = c->p.index_interval;
+    for (uint32_t i = 0; i < n; i++) {
+        const basal_read &r = reads[i];
+        if (r.len == 0) continue;
+        if (r.len > BASAL_MAXREADLEN || (uint64_t)r.seq_off + r.len > nbases) { g_err = "align_batch: read descriptor out of range"; return BASAL_EINVAL; }
+        if (r.max_snp > BASAL_MAXSNPS) { g_err = "align_batch: max_snp > 15"; return BASAL_EINVAL; }
+        if (r.stale_src < n) {
+            const basal_read &s = reads[r.stale_src];
+            if (r.stale_src >= i || s.len == 0 || s.len < K + I - 1) { g_err = "align_batch: stale_src must name an earlier aligned read"; return BASAL_EINVAL; }
+        }
+        if (r.len > max_len) max_len = r.len;
+    }
+    int rc;
+    size_t cap_res = c->cap_reads;
+    if ((rc = grow(c->d_bases, c->cap_bases, nbases + 64))) return rc;
+    if (n > c->cap_reads) {
+        hipFree(c->d_results);
+        c->d_results = nullptr;
+    }
+    if ((rc = grow(c->d_reads, c->cap_reads, n))) return rc;
+    if (!c->d_results) HIP_TRY(hipMalloc(&c->d_results, c->cap_reads * sizeof(basal_result)));
+    (void)cap_res;
+    if (stream_mode != BASAL_STREAM_NONE)
+        if ((rc = grow(c->d_stream, c->cap_stream, stream_cap ? stream_cap : 1))) return rc;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_bases, bases, nbases, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(c->d_used, 0, sizeof(unsigned long long), s));
+    static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
+    rc = launch_align(c, c->d_bases, c->d_reads, n, max_len, stream_mode, c->d_results, c->d_stream, stream_cap, c->d_used,
+                      carry ? (const uint8_t(*)[2])carry : zero_carry, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(results, c->d_results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, s));
+    unsigned long long used = 0;
+    HIP_TRY(hipMemcpyAsync(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (stream_used) *stream_used = used;
+    int ret = BASAL_OK;
+    if (stream_mode != BASAL_STREAM_NONE) {
+        if (used > stream_cap) { g_err = "align_batch: hit stream too small; needed " + std::to_string(used); ret = BASAL_EOVERFLOW; }
+        uint64_t ncopy = used < stream_cap ? used : stream_cap;
+        if (ncopy) HIP_TRY(hipMemcpy(stream, c->d_stream, ncopy * sizeof(basal_hit), hipMemcpyDeviceToHost));
+    }
+    // carry: xseed_start_offset after the last read of each slot that defined it (align.cpp:475-480)
+    if (carry) {
+        for (int slot = 0; slot < 2; slot++) {
+            for (uint32_t i = n; i-- > 0;) {
+                const basal_read &r = reads[i];
+                if (r.len == 0 || (r.readset == 2 ? 1 : 0) != slot) continue;
+                if (results[i].status == BASAL_READ_SKIPPED) continue;
+                // any aligned read leaves a defined value behind (own or inherited)
+                bool f0 = (c->p.chains == 1) || ((c->p.chains <= 1) == (r.readset < 2));
+                bool f1 = (c->p.chains == 1) || ((c->p.chains <= 1) == (r.readset == 2));
+                if (f0) carry[slot][0] = results[i].start_off[0];
+                if (f1) carry[slot][1] = results[i].start_off[1];
+                break;
+            }
+        }
+    }
+    return ret;
+}
+
+extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, uint64_t nblocks, uint32_t *max_kmer_num_out) {
+    (void)c; (void)blocks; (void)nblocks; (void)max_kmer_num_out;
+    g_err = "build_index: GPU index build not implemented yet";
+    return BASAL_ESTATE;
+}

@@ -1,0 +1,219 @@
+/*
+ * basal_core.h -- C ABI of the MI355X-native BASAL alignment core (libbasal_amd.so).
+ *
+ * This is the drop-in boundary for the seed-and-extend hot path of JiejunShi/BASAL.  The
+ * reference has no plugin API; the seam is the SingleAlign object that its host drives
+ * (align.h:29-116), used from main.cpp:60-84 (t_SingleAlign: ImportBatchReads -> Do_Batch ->
+ * _str_align) and from pairs.cpp:132-202 (PairAlign drives two SingleAligns mode by mode).
+ * Each entry point below names the reference interface it replaces.  Plain pointers and
+ * sizes only; no C++/HIP/torch types cross this boundary.  All functions return 0 on success
+ * or a negative BASAL_E* code (the reference exit(1)s instead); basal_last_error() gives text.
+ *
+ * Two groups:
+ *   basal_core_*  the GPU core: reference + seed index resident in HBM, batches of reads in,
+ *                 fixed-size hit records out.  Replaces SingleAlign::{RunAlign, ConvertBina(r)ySeq,
+ *                 ReorderSeed, SnpAlign, GapAlign, AddHit, int2hit} and the hit selection of
+ *                 StringAlign (align.cpp:79-612).
+ *   basal_host_*  host-side helpers that produce exactly what the core consumes and turn
+ *                 what it emits into SAM: Param::SetAlign (param.cpp:163-263), RefSeq::
+ *                 Run_ConvertBinseq/CreateIndex (refbase.cpp:186-439), FilterReads
+ *                 (align.cpp:548-563), s_OutHit (align.cpp:616-669).  The `basal` CLI is built
+ *                 from these; a maintainer of the reference would call basal_core_* from
+ *                 SingleAlign::Do_Batch instead.
+ */
+#ifndef BASAL_CORE_H
+#define BASAL_CORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BASAL_OK 0
+#define BASAL_EINVAL (-1)   /* bad argument / unsupported parameter combination */
+#define BASAL_ENOMEM (-2)   /* host or device allocation failed */
+#define BASAL_EDEVICE (-3)  /* HIP runtime error, or no gfx950 device */
+#define BASAL_ESTATE (-4)   /* call order (e.g. align before set_reference) */
+#define BASAL_EOVERFLOW (-5)/* hit stream capacity too small; results for flagged reads incomplete */
+#define BASAL_EIO (-6)
+
+#define BASAL_MAXSNPS 15    /* param.h:18 */
+#define BASAL_MAXGAPS 3     /* param.h:19 */
+#define BASAL_MAXHITS 1000  /* makefile:4 */
+#define BASAL_MAXREADLEN 480 /* (FIXELEMENT-1)*SEGLEN, param.cpp:58 */
+#define BASAL_REF_MARGIN 400 /* refbase.h:16, in 64-bit words */
+
+/* Every Param field the hot path reads (param.h:44-148) plus the 2-bit code tables that
+ * Param::SetAlign derives from -M (param.cpp:163-263). Fill with basal_host_params_*. */
+typedef struct basal_params {
+    uint32_t seed_size;          /* -s, 10..16 */
+    uint32_t index_interval;     /* -I, 1..16 */
+    uint32_t max_snp_num;        /* -v as stored by main.cpp:324-338 (>=100 means percent+100) */
+    uint32_t max_num_hits;       /* -w, <=1000 */
+    uint32_t chains;             /* -n */
+    uint32_t randseed;           /* -S; 0 is not reproducible in the reference, here it is the hash RNG with seed 0 */
+    uint32_t gap;                /* -g, <=3 */
+    uint32_t gap_edge;           /* 6 */
+    uint32_t n_mis;              /* hidden -N */
+    uint32_t new_rule;           /* 1: CountMismatch_new/MismatchPattern*_new (align.cpp:300) */
+    uint32_t report_repeat_hits; /* -r */
+    uint32_t pairend;
+    uint32_t max_ns, min_read_size, max_readlen, trim_qual_threshold, n_adapter;
+    uint32_t out_ref, out_unmap, min_insert, max_insert;
+    float max_kmer_ratio;        /* -k */
+    uint8_t zero_qual, default_qual, pad0, pad1;
+    char adapter[10][128];
+    char refnt, readnts[5];
+    uint8_t readnt_cnt, pad2;
+    uint8_t alphabet[256], rev_alphabet[256], reg_alphabet[256];
+    uint8_t alphabet_mread[256], rev_alphabet_mread[256];
+    char useful_nt[12];
+} basal_params;
+
+/* One stored alignment: gHit (param.h:35-42) plus where AddHit (align.h:329-347) put it. */
+typedef struct basal_hit {
+    uint32_t loc;      /* 0-based on the forward strand of the contig */
+    uint32_t chr;      /* 2*contig + ref_strand, 18 bits like the reference's bit-field */
+    int8_t gap_size;   /* >0 deletion from the read (CIGAR D), <0 insertion (CIGAR I) */
+    uint8_t strand;    /* (ref_strand<<1)|read_chain */
+    uint16_t gap_pos;  /* 9 bits */
+    uint8_t level;     /* mismatch level w the hit was stored at (xhits[chain][w]) */
+    uint8_t chain;     /* read chain: 0 as sequenced, 1 reverse complement */
+    uint8_t mode;      /* SnpAlign mode (seed segment rank) that produced it; PE truncation */
+    uint8_t pad;
+} basal_hit;
+
+/* Per-read summary: what StringAlign (align.cpp:583-612) needs. 32 bytes. */
+typedef struct basal_result {
+    basal_hit best;       /* the hit printed for a unique read or for -r 1 (myrand pick); valid if best_level!=0xFF */
+    uint16_t n_hit;       /* _cur_n_hit[best_level]  */
+    uint16_t n_chit;      /* _cur_n_chit[best_level] */
+    uint8_t best_level;   /* lowest non-empty level, 0xFF if the read has no hit */
+    uint8_t start_off[2]; /* xseed_start_offset[chain] after this read (align.cpp:475-480 carry) */
+    uint8_t status;       /* BASAL_READ_* */
+    uint32_t stream_first;/* first record of this read in the hit stream */
+    uint32_t stream_n;    /* number of records of this read in the hit stream */
+} basal_result;
+
+#define BASAL_READ_OK 0
+#define BASAL_READ_SKIPPED 1   /* len==0 descriptor (QC-failed on the host) */
+#define BASAL_READ_OVERFLOW 2  /* hit stream full: stream_n is what was needed, nothing written */
+
+/* One read as FilterReads (align.cpp:548-563) leaves it. 16 bytes. */
+typedef struct basal_read {
+    uint32_t seq_off;   /* offset of the first base in the batch's base buffer */
+    uint32_t index;     /* ReadInf.index: global read number, feeds myrand */
+    uint16_t len;       /* 0: skip */
+    uint8_t readset;    /* 0 SE, 1 mate 1, 2 mate 2 */
+    uint8_t max_snp;    /* read_max_snp_num */
+    uint32_t stale_src; /* where xseed_start_offset comes from when (len-I+1)%k==0:
+                           BASAL_STALE_NONE, BASAL_STALE_CARRY, or a read number in this batch */
+} basal_read;
+#define BASAL_STALE_NONE 0xFFFFFFFFu
+#define BASAL_STALE_CARRY 0xFFFFFFFEu
+
+/* what goes into the hit stream */
+#define BASAL_STREAM_NONE 0 /* -r 0/1 SE: basal_result.best is enough */
+#define BASAL_STREAM_BEST 1 /* -r 2 SE: all hits of the best level, chain 0 then chain 1, insertion order */
+#define BASAL_STREAM_ALL 2  /* PE: every stored hit, insertion order, tagged with level/chain/mode */
+
+typedef struct basal_core basal_core_t;
+
+/* ---- GPU core ---- */
+/* device: HIP device ordinal. Replaces `SingleAlign a;` (main.cpp:61). */
+int basal_core_create(const basal_params *p, int device, basal_core_t **out);
+void basal_core_destroy(basal_core_t *c);
+
+/* Stage the 2-bit reference (RefSeq::xref[2], ref_anchor, title; refbase.cpp:186-252) and the
+ * seed index (RefSeq::index2, refbase.cpp:261-439, flattened: kmer_off[3^k+1] CSR offsets into
+ * locs, kmer_nfwd[3^k] = number of forward-strand entries of each k-mer) into HBM, once.
+ * Host pointers; the core copies. */
+int basal_core_set_reference(basal_core_t *c, const uint64_t *xref_fwd, const uint64_t *xref_rc, uint64_t nwords,
+                             const uint32_t *ref_anchor, const uint32_t *contig_size, const uint32_t *rc_offset,
+                             uint32_t ncontig);
+int basal_core_set_index(basal_core_t *c, const uint32_t *kmer_off, const uint32_t *kmer_nfwd, const uint32_t *locs,
+                         uint64_t nlocs, uint32_t max_kmer_num);
+/* Build the seed index on the GPU from the staged reference (same result as set_index with the
+ * host-built arrays; refbase.cpp:261-439). blocks = RefSeq::_blocks (id,begin,end triples). */
+int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, uint64_t nblocks, uint32_t *max_kmer_num_out);
+/* Copy the device index back (tests; handing the index to a CPU baseline). Any pointer may be NULL. */
+int basal_core_get_index(basal_core_t *c, uint32_t *kmer_off, uint32_t *kmer_nfwd, uint32_t *locs, uint64_t *nlocs,
+                         uint32_t *max_kmer_num);
+
+/* Align one batch; host buffers in, host buffers out. Replaces SingleAlign::Do_Batch's RunAlign
+ * loop (align.cpp:565-580). carry[slot][chain]: xseed_start_offset inherited from the previous
+ * batch (slot 0: SE reads and mate 1, slot 1: mate 2); updated on return.
+ * stream may be NULL when stream_mode==BASAL_STREAM_NONE. */
+int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n,
+                           int stream_mode, basal_result *results, basal_hit *stream, uint64_t stream_cap,
+                           uint64_t *stream_used, uint8_t carry[2][2]);
+
+/* Same, but every buffer is already resident in HBM (device pointers) and the work is queued on
+ * `stream` (a hipStream_t passed as void*, NULL = the null stream) without synchronising.
+ * d_stream_used: device uint64 counter, must be zero on entry. max_len: an upper bound of the read
+ * lengths in the batch (<=480); it selects the kernel instantiation (reads longer than it are skipped).  This is the entry point the
+ * benchmark times and the one a multi-GPU driver uses before its RCCL gather of results. */
+int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const void *d_reads, uint32_t n, int stream_mode,
+                                  void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used,
+                                  const uint8_t carry[2][2], uint32_t max_len, void *hip_stream);
+
+/* Kernel-time instrumentation: milliseconds of the last align_batch* kernel measured with HIP
+ * events on the stream it ran on (0 if timing is off). */
+int basal_core_set_timing(basal_core_t *c, int on);
+float basal_core_last_kernel_ms(basal_core_t *c);
+/* launch geometry actually used (blocks, threads per block, waves) for reporting */
+int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_t *threads, uint32_t *lds_bytes);
+
+const char *basal_last_error(void);
+
+/* ---- host helpers ---- */
+void basal_host_params_defaults(basal_params *p);                    /* Param::Param, param.cpp:7-68 */
+int basal_host_params_set_seed_size(basal_params *p, int n);         /* Param::SetSeedSize, param.cpp:108-115 */
+int basal_host_params_set_align(basal_params *p, const char *rule);  /* Param::SetAlign, param.cpp:163-263 */
+void basal_host_params_set_v(basal_params *p, double v);             /* main.cpp:324-338 */
+
+typedef struct basal_ref basal_ref_t; /* RefSeq without the index arrays' ownership rules */
+/* RefSeq::Run_ConvertBinseq (refbase.cpp:186-252) from a FASTA file (plain or .gz) or memory. */
+int basal_host_ref_load(const basal_params *p, const char *fasta_path, basal_ref_t **out);
+int basal_host_ref_load_mem(const basal_params *p, const char *buf, size_t len, basal_ref_t **out);
+void basal_host_ref_free(basal_ref_t *r);
+/* views into the loaded reference (owned by r) */
+uint32_t basal_host_ref_ncontig(const basal_ref_t *r);
+const char *basal_host_ref_name(const basal_ref_t *r, uint32_t contig);
+const uint32_t *basal_host_ref_sizes(const basal_ref_t *r);
+const uint32_t *basal_host_ref_rc_offsets(const basal_ref_t *r);
+const uint32_t *basal_host_ref_anchors(const basal_ref_t *r);
+uint64_t basal_host_ref_nwords(const basal_ref_t *r);
+const uint64_t *basal_host_ref_words(const basal_ref_t *r, int strand);
+uint64_t basal_host_ref_nblocks(const basal_ref_t *r);
+const uint32_t *basal_host_ref_blocks(const basal_ref_t *r); /* (id,begin,end) triples, sorted */
+/* RefSeq::CreateIndex on the CPU (refbase.cpp:261-439): fills the flattened index inside r. */
+int basal_host_ref_build_index(basal_ref_t *r, const basal_params *p, int threads);
+uint32_t basal_host_ref_total_kmers(const basal_ref_t *r);
+const uint32_t *basal_host_ref_kmer_off(const basal_ref_t *r);
+const uint32_t *basal_host_ref_kmer_nfwd(const basal_ref_t *r);
+const uint32_t *basal_host_ref_locs(const basal_ref_t *r);
+uint64_t basal_host_ref_nlocs(const basal_ref_t *r);
+uint32_t basal_host_ref_max_kmer_num(const basal_ref_t *r);
+/* convenience: set_reference + (set_index | build_index) */
+int basal_host_ref_upload(const basal_ref_t *r, basal_core_t *c, int build_index_on_gpu, uint32_t *max_kmer_num);
+
+/* FilterReads (align.cpp:548-563): trims seq/qual in place (NUL-terminated, caller-owned,
+ * qual buffer at least as long as seq), returns 1 if the read fails QC, else 0 with
+ * *read_max_snp_num set. */
+int basal_host_filter_read(const basal_params *p, char *seq, char *qual, uint32_t *read_max_snp_num);
+
+/* SAM text for one SE read: StringAlign + s_OutHit (align.cpp:583-669). status: 0 aligned
+ * normally, 1 QC-failed. Appends to a caller buffer; returns bytes written or <0 (BASAL_EOVERFLOW
+ * if cap is too small; nothing is written then). */
+int64_t basal_host_format_se(const basal_params *p, const basal_ref_t *r, const char *name, const char *seq,
+                             const char *qual, uint32_t readset, int qc_failed, const basal_result *res,
+                             const basal_hit *stream, char *out, size_t cap);
+int64_t basal_host_sam_header(const basal_ref_t *r, const char *cmdline, char *out, size_t cap); /* main.cpp:586-597 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

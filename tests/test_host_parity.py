@@ -1,0 +1,136 @@
+"""Product host code (libbasal_amd.so, no GPU call) against the oracle: -M code tables, the packed
+reference, blocks, the seed index and its cut-off, FilterReads, and the exported ABI."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+import basal_amd as B
+from basal_amd import core as bc
+import harness as H
+import oracle as orc
+
+RULES = ["C:T", "A:G", "A:CGT", "T:-", "G:ACT-", "T:C", "G:A", "c:t", "A:GG", "C:TA-"]
+
+
+@pytest.mark.parametrize("rule", RULES)
+def test_set_align_tables(rule):
+    p = B.Params(rule)
+    o = orc.make_param(["-M", rule])
+    for f in ("alphabet", "rev_alphabet", "reg_alphabet", "alphabet_mread", "rev_alphabet_mread"):
+        assert bytes(getattr(p.c, f)) == bytes(getattr(o, f)), f
+    assert p.c.useful_nt[:8] == o.useful_nt[:8]
+    assert p.c.new_rule == o.new_rule
+    assert p.c.readnt_cnt == o.readnt_cnt
+
+
+def test_known_code_tables():
+    """C:T -> A0 C1 G2 T3; A:G -> A1 C0 G3 T2; A:CGT -> A1 C0 G2 T3; T:- -> T1 A0 C2 G3."""
+    want = {"C:T": dict(A=0, C=1, G=2, T=3), "A:G": dict(A=1, C=0, G=3, T=2), "A:CGT": dict(A=1, C=0, G=2, T=3),
+            "T:-": dict(T=1, A=0, C=2, G=3)}
+    for rule, tab in want.items():
+        p = B.Params(rule)
+        for b, code in tab.items():
+            assert p.c.alphabet[ord(b)] == code and p.c.alphabet[ord(b.lower())] == code
+
+
+@pytest.mark.parametrize("bad", ["CT", "N:T", "C:C", "C:X", ""])
+def test_set_align_rejects(bad):
+    with pytest.raises(B.BasalError):
+        B.Params(bad)
+
+
+def test_param_flag_order_min_read_size():
+    # -s sets min_read_size = k + I - 1 with I as parsed so far (param.cpp:112); default stays 16 (param.cpp:34)
+    assert B.Params("C:T").c.min_read_size == 16
+    assert B.Params("C:T", ["-s", "12"]).c.min_read_size == 15
+    assert B.Params("C:T", ["-I", "2", "-s", "12"]).c.min_read_size == 13
+    assert B.Params("C:T", ["-s", "12", "-I", "2"]).c.min_read_size == 15
+    for fl in ([], ["-s", "12"], ["-I", "2", "-s", "12"], ["-s", "12", "-I", "2"]):
+        assert B.Params("C:T", fl).c.min_read_size == orc.make_param(["-M", "C:T"] + fl).min_read_size
+
+
+@pytest.mark.parametrize("name", ["ct_n1_dirty", "tx_ag_150", "rep_r1", "v_frac05_I2", "acgt_g2"])
+def test_reference_and_index_match_oracle(name):
+    fa = H.fixture_paths(name)[0]
+    flags = H.MANIFEST[name]["flags"]
+    p = B.Params(H.rule_of(flags), flags)
+    ref = B.Reference(p, fasta_path=fa)
+    o = orc.Oracle(flags, fa)
+    a = o.arrays()
+    assert ref.names() == a["names"]
+    assert np.array_equal(ref.sizes(), a["size"])
+    assert np.array_equal(ref.rc_offsets(), a["rc_offset"])
+    assert np.array_equal(ref.anchors(), a["anchor"])
+    assert np.array_equal(ref.words(0), a["xref0"])
+    assert np.array_equal(ref.words(1), a["xref1"])
+    for threads in (1, 3):
+        ref.build_index(threads)
+        off, nfwd, locs, mk = ref.index()
+        assert np.array_equal(off.astype(np.uint64), a["off"])
+        assert np.array_equal(nfwd, a["n_fwd"])
+        assert np.array_equal(locs, a["locs"])
+        assert mk == a["max_kmer_num"]
+    o.close()
+
+
+def test_default_seed_size_index_cutoff():
+    """k=16: the cut-off index is computed in single precision (refbase.cpp:363) -> 43046699."""
+    name = "c1_s16"
+    fa = H.fixture_paths(name)[0]
+    flags = H.MANIFEST[name]["flags"]
+    p = B.Params("C:T", flags)
+    ref = B.Reference(p, fasta_path=fa)
+    ref.build_index(4)
+    o = orc.Oracle(flags, fa)
+    a = o.arrays()
+    off, nfwd, locs, mk = ref.index()
+    assert mk == a["max_kmer_num"]
+    assert np.array_equal(locs, a["locs"]) and np.array_equal(nfwd, a["n_fwd"])
+    o.close()
+
+
+@pytest.mark.parametrize("name,extra", [("varlen_trim", []), ("ct_n1_dirty", []), ("varlen_s16", ["-q", "30"]),
+                                         ("ct_basic", ["-A", "AGATCGGAAGAGC", "-q", "20", "-z", "64"])])
+def test_filter_reads_matches_oracle(name, extra):
+    fa, fq, _, _ = H.fixture_paths(name)
+    flags = H.MANIFEST[name]["flags"] + extra
+    p = B.Params(H.rule_of(flags), flags)
+    o = orc.Oracle([f for f in flags], fa)
+    reads = orc.read_fastx(fq)
+    # make the extra-flag cases bite: low-quality tails and adapter read-through
+    if extra:
+        reads = [(n, s[:60] + "AGATCGGAAGAGCACACG"[: max(0, len(s) - 60)] if i % 3 == 0 else s,
+                  (q[:-15] + "#" * 15) if i % 2 == 0 else q) for i, (n, s, q) in enumerate(reads)]
+        reads = [(n, s, q[: len(s)].ljust(len(s), "I")) for n, s, q in reads]
+    mine = H.filter_reads(p, reads)
+    for i, ((n, s, q), m) in enumerate(zip(reads, mine)):
+        s2, q2 = s[: p.c.max_readlen], q[: p.c.max_readlen]
+        ref = o.align(i, 0, n, s2, q2)
+        assert bool(m["qc"]) == ref["filtered"], (i, n)
+        assert m["seq"] == ref["seq"] and m["qual"] == ref["qual"], (i, n)
+        if not ref["filtered"]:
+            assert m["max_snp"] == ref["max_snp"], (i, n)
+    o.close()
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(H.ROOT, "include", "basal_core.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(basal_(?:core|host|last)_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    L = C.CDLL(B.lib_path())
+    for s in sorted(declared):
+        assert hasattr(L, s), "libbasal_amd.so does not export " + s
+    assert declared == {n for n, _, _ in bc.SYMBOLS}
+
+
+def test_core_fails_loudly_without_gpu():
+    """No CPU fallback: without a HIP device creating the core is an error, not a silent slow path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(B.BasalError):
+        B.Core(B.Params("C:T"))
