@@ -16,7 +16,7 @@ class BasalError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libbasal_amd.so")
+    return os.environ.get("BASAL_LIB") or os.path.join(_HERE, "lib", "libbasal_amd.so")
 
 
 def build(verbose=False):
@@ -50,7 +50,11 @@ class basal_result(C.Structure):
 
 class basal_read(C.Structure):
     _fields_ = [("seq_off", C.c_uint32), ("index", C.c_uint32), ("len", C.c_uint16), ("readset", C.c_uint8),
-                ("max_snp", C.c_uint8), ("stale_src", C.c_uint32)]
+                ("max_snp", C.c_uint8), ("stale_idx", C.c_uint32)]
+
+
+class basal_stale(C.Structure):
+    _fields_ = [("src", C.c_uint32), ("overlay", (C.c_uint32 * 15) * 2)]
 
 
 HIT_DTYPE = np.dtype([("loc", "<u4"), ("chr", "<u4"), ("gap_size", "i1"), ("strand", "u1"), ("gap_pos", "<u2"),
@@ -58,9 +62,11 @@ HIT_DTYPE = np.dtype([("loc", "<u4"), ("chr", "<u4"), ("gap_size", "i1"), ("stra
 RESULT_DTYPE = np.dtype([("best", HIT_DTYPE), ("n_hit", "<u2"), ("n_chit", "<u2"), ("best_level", "u1"),
                          ("start_off", "u1", (2,)), ("status", "u1"), ("stream_first", "<u4"), ("stream_n", "<u4")])
 READ_DTYPE = np.dtype([("seq_off", "<u4"), ("index", "<u4"), ("len", "<u2"), ("readset", "u1"), ("max_snp", "u1"),
-                       ("stale_src", "<u4")])
+                       ("stale_idx", "<u4")])
+STALE_DTYPE = np.dtype([("src", "<u4"), ("overlay", "<u4", (2, 15))])
 assert HIT_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 32 and READ_DTYPE.itemsize == 16
 assert C.sizeof(basal_hit) == 16 and C.sizeof(basal_result) == 32 and C.sizeof(basal_read) == 16
+assert C.sizeof(basal_stale) == 124 and STALE_DTYPE.itemsize == 124
 
 _lib = None
 
@@ -74,8 +80,8 @@ SYMBOLS = [
     ("basal_core_set_index", _i, [_vp, _vp, _vp, _vp, _u64, _u32]),
     ("basal_core_build_index", _i, [_vp, _vp, _u64, _P(_u32)]),
     ("basal_core_get_index", _i, [_vp, _vp, _vp, _vp, _P(_u64), _P(_u32)]),
-    ("basal_core_align_batch", _i, [_vp, _vp, _u64, _vp, _u32, _i, _vp, _vp, _u64, _P(_u64), _vp]),
-    ("basal_core_align_batch_device", _i, [_vp, _vp, _vp, _u32, _i, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
+    ("basal_core_align_batch", _i, [_vp, _vp, _u64, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _P(_u64), _vp]),
+    ("basal_core_align_batch_device", _i, [_vp, _vp, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
     ("basal_core_set_timing", _i, [_vp, _i]),
     ("basal_core_last_kernel_ms", C.c_float, [_vp]),
     ("basal_core_launch_info", _i, [_vp, _P(_u32), _P(_u32), _P(_u32)]),
@@ -104,6 +110,10 @@ SYMBOLS = [
     ("basal_host_ref_nlocs", _u64, [_vp]),
     ("basal_host_ref_max_kmer_num", _u32, [_vp]),
     ("basal_host_ref_upload", _i, [_vp, _vp, _i, _P(_u32)]),
+    ("basal_host_stale_new", _vp, [_P(basal_params)]),
+    ("basal_host_stale_free", None, [_vp]),
+    ("basal_host_stale_begin_batch", None, [_vp]),
+    ("basal_host_stale_visit", _i, [_vp, C.c_char_p, _u32, _u32, _i, _u32, _P(basal_stale)]),
     ("basal_host_filter_read", _i, [_P(basal_params), C.c_char_p, C.c_char_p, _P(_u32)]),
     ("basal_host_format_se", C.c_int64, [_P(basal_params), _vp, C.c_char_p, C.c_char_p, C.c_char_p, _u32, _i,
                                          _P(basal_result), _vp, C.c_char_p, C.c_size_t]),
@@ -286,8 +296,8 @@ class Core:
         _check(L.basal_core_get_index(self.h, off.ctypes.data, nf.ctypes.data, locs.ctypes.data, C.byref(n), C.byref(mk)), "get_index")
         return off, nf, locs, mk.value
 
-    def align_batch(self, bases, reads, stream_mode=STREAM_NONE, stream_cap=0, carry=None):
-        """bases: uint8 array; reads: READ_DTYPE array. Returns (results, stream, carry)."""
+    def align_batch(self, bases, reads, stream_mode=STREAM_NONE, stream_cap=0, carry=None, stales=None):
+        """bases: uint8 array; reads: READ_DTYPE array; stales: STALE_DTYPE array. Returns (results, stream, carry)."""
         n = len(reads)
         res = np.zeros(n, RESULT_DTYPE)
         stream = np.zeros(max(stream_cap, 1), HIT_DTYPE)
@@ -295,7 +305,9 @@ class Core:
         cy = np.zeros((2, 2), np.uint8) if carry is None else np.array(carry, np.uint8).reshape(2, 2).copy()
         bases = np.ascontiguousarray(bases, np.uint8)
         reads = np.ascontiguousarray(reads)
-        rc = lib().basal_core_align_batch(self.h, bases.ctypes.data, len(bases), reads.ctypes.data, n, stream_mode,
+        stales = np.zeros(0, STALE_DTYPE) if stales is None else np.ascontiguousarray(stales)
+        rc = lib().basal_core_align_batch(self.h, bases.ctypes.data, len(bases), reads.ctypes.data, n,
+                                          stales.ctypes.data if len(stales) else None, len(stales), stream_mode,
                                           res.ctypes.data, stream.ctypes.data if stream_mode else None, stream_cap,
                                           C.byref(used), cy.ctypes.data)
         _check(rc, "align_batch")

@@ -55,6 +55,8 @@ struct DevCtx {
     const uint8_t *bases;
     const basal_read *reads;
     uint32_t n;
+    const basal_stale *stales;
+    uint32_t nstale;
     basal_result *results;
     basal_hit *stream;
     unsigned long long stream_cap;
@@ -63,7 +65,24 @@ struct DevCtx {
     uint32_t scratch_per_wave;
     unsigned int *work_counter;
     uint8_t carry[2][2];
+    // bounds of the gathered arrays and a fault ledger: an index outside its array is clamped and
+    // counted (per kind) instead of being dereferenced, so an internal error surfaces as
+    // BASAL_EDEVICE on the host rather than as a GPU memory fault
+    uint32_t total_kmers, nlocs;
+    unsigned long long nwords, nbases;
+    unsigned int *guard;  // [0..7] counts, [8..15] first offending value, [16..23] read number
 };
+
+enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 5, G_KMER2 = 6, G_WATCHDOG = 7 };
+
+__device__ __forceinline__ unsigned long long guard_idx(const DevCtx &cx, int kind, unsigned long long idx, unsigned long long lim, uint32_t r) {
+    if (idx < lim) return idx;
+    if (atomicAdd(&cx.guard[kind], 1u) == 0) {
+        cx.guard[8 + kind] = (unsigned int)idx;
+        cx.guard[16 + kind] = r;
+    }
+    return 0;
+}
 
 struct SeedEnt {  // one (chain, phase) seed of the current mode
     uint32_t off, m, nfwd, h, jj0, pre;  // pre = number of candidates before this seed in the mode's stream
@@ -88,6 +107,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// "Is this lane 0?" with the lane id laundered through an empty asm: LLVM must not correlate two
+// such tests. Without this, jump threading joined the `if (lane0(lane)) store` that ends one read
+// with the `if (lane0(lane)) atomicAdd` that fetches the next, so lane 0 and lanes 1..63 ran the
+// work loop on separate paths and the wave-level operations (readfirstlane, ballot) saw partial
+// waves: lanes 1..63 re-ran read 0 with lane 0 missing (found on MI355X, ROCm 7.2, -O2/-O3).
+__device__ __forceinline__ bool lane0(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane == 0;
 }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -130,8 +159,10 @@ struct ReadCtx {
     uint32_t len, index, readset, max_snp, seq_off;
     uint32_t nseg, ii, npos;
     uint32_t end_element, end_offset;
-    uint32_t flag[2];
+    uint32_t flags;  // bit c: read chain c is aligned (xflag_chain)
     uint32_t n_count;
+    uint32_t rno;  // read number in the batch (diagnostics)
+    __device__ __forceinline__ bool on(int c) const { return (flags >> c) & 1u; }
 };
 
 // ---- steps 1+2: pack, hash seeds, gather counts --------------------------------------------
@@ -143,8 +174,8 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
     rc.max_snp = rd.max_snp;
     rc.seq_off = rd.seq_off;
     // xflag_chain (align.cpp:83-84)
-    rc.flag[0] = (cx.chains == 1) || ((cx.chains <= 1) == (rd.readset < 2));
-    rc.flag[1] = (cx.chains == 1) || ((cx.chains <= 1) == (rd.readset == 2));
+    rc.flags = (((cx.chains == 1) || ((cx.chains <= 1) == (rd.readset < 2))) ? 1u : 0u) |
+               (((cx.chains == 1) || ((cx.chains <= 1) == (rd.readset == 2))) ? 2u : 0u);
     {  // seedseg_num (align.cpp:450)
         int x = (int)((rc.len - cx.I + 1) / cx.K), y = (int)(rc.max_snp + 1);
         rc.nseg = (uint32_t)(x < y ? x : y);
@@ -153,32 +184,31 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
     rc.npos = rc.len >= cx.K ? rc.len - cx.K + 1 : 0;
     rc.end_element = (rc.len - 1) / 32;                    // align.cpp:442
     rc.end_offset = (32 - ((rc.len - 1) % 32 + 1)) << 1;   // align.cpp:443
-    const uint8_t *seq = cx.bases + rc.seq_off;
     uint32_t nblk = (rc.len + 63) / 64;
     uint32_t ncnt = 0;
     for (int c = 0; c < 2; c++) {
-        if (!rc.flag[c]) continue;
+        if (!rc.on(c)) continue;
         const uint8_t *al = tab + (c ? 256 : 0), *am = tab + (c ? 1024 : 768), *rg = tab + 512;
         for (uint32_t b = 0; b <= (uint32_t)NWT / 2; b++) {
             uint32_t pos = b * 64 + lane;
             uint32_t ch = 0;
-            if (b < nblk && pos < rc.len) ch = seq[c ? rc.len - 1 - pos : pos];
+            if (b < nblk && pos < rc.len) ch = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + (c ? rc.len - 1 - pos : pos), cx.nbases, rc.rno)];
             uint64_t a0, a1, v0, v1, m0, m1;
             uint32_t valid = rg[ch];
             pack_codes(al[ch], a0, a1);
             pack_codes(valid, v0, v1);
             pack_codes(am[ch], m0, m1);
             if (c == 0) ncnt += __popcll(__ballot(b < nblk && pos < rc.len && !valid));
-            if (lane == 0) {
+            if (lane0(lane)) {
                 if (2 * b < (uint32_t)NWT + 1) { L.q[c][0][2 * b] = a0; L.q[c][1][2 * b] = v0; L.q[c][2][2 * b] = m0; }
                 if (2 * b + 1 < (uint32_t)NWT + 1) { L.q[c][0][2 * b + 1] = a1; L.q[c][1][2 * b + 1] = v1; L.q[c][2][2 * b + 1] = m1; }
             }
         }
     }
-    if (!rc.flag[0]) {  // count N's when only chain 1 is packed (CountNs, align.cpp:40-47)
+    if (!rc.on(0)) {  // count N's when only chain 1 is packed (CountNs, align.cpp:40-47)
         for (uint32_t b = 0; b < nblk; b++) {
             uint32_t pos = b * 64 + lane;
-            uint32_t ch = pos < rc.len ? seq[pos] : 'A';
+            uint32_t ch = pos < rc.len ? cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + pos, cx.nbases, rc.rno)] : 'A';
             ncnt += __popcll(__ballot(!tab[512 + ch]));
         }
     }
@@ -187,7 +217,7 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
     // seeds: xseed_array / xseedreg_array (align.cpp:92-100) and their index counts
     const uint32_t kbits = 2 * cx.K;
     for (int c = 0; c < 2; c++) {
-        if (!rc.flag[c]) continue;
+        if (!rc.on(c)) continue;
         for (uint32_t p = lane; p < (uint32_t)WaveLds<NWT>::MAXPOS; p += 64) {
             uint32_t sd = 0x80000000u, ct = 0;  // out-of-read positions: "contains N", count 0
             if (p < rc.npos) {
@@ -199,7 +229,7 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
                 }
                 uint32_t s = (uint32_t)(a >> (64 - kbits)), sb = (uint32_t)(b >> (64 - kbits));
                 uint32_t full = kbits == 32 ? 0xFFFFFFFFu : ((1u << kbits) - 1);
-                sd = XT(s);
+                sd = (uint32_t)guard_idx(cx, G_KMER, XT(s), cx.total_kmers, rc.rno);
                 ct = cx.kmer_off[sd + 1] - cx.kmer_off[sd];
                 if ((~sb) & full) sd |= 0x80000000u;
             }
@@ -238,11 +268,11 @@ __device__ uint32_t best_start_offset(const DevCtx &cx, const WaveLds<NWT> &L, c
 
 // ---- step 3: ReorderSeed ------------------------------------------------------------------
 template <int NWT>
-__device__ void reorder_seed(const DevCtx &cx, WaveLds<NWT> &L, const ReadCtx &rc, int lane, const uint32_t so[2]) {
+__device__ void reorder_seed(const DevCtx &cx, WaveLds<NWT> &L, const ReadCtx &rc, int lane, uint32_t so0, uint32_t so1) {
     uint32_t max_offset = rc.ii;
     for (int c = 0; c < 2; c++) {
-        if (!rc.flag[c]) continue;
-        if ((uint32_t)lane < 16) L.start_arr[c][lane] = (uint8_t)so[c];
+        if (!rc.on(c)) continue;
+        if ((uint32_t)lane < 16) L.start_arr[c][lane] = (uint8_t)(c ? so1 : so0);
         wave_sync();
         // AdjustSeedStartArray (align.cpp:500-524)
         for (uint32_t i = 0; i < rc.nseg; i++) {
@@ -255,7 +285,7 @@ __device__ void reorder_seed(const DevCtx &cx, WaveLds<NWT> &L, const ReadCtx &r
             uint32_t m = wave_min(tt);
             uint32_t pick = start;
             if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)__ballot(valid && tt == m)) - 1;
-            if (lane == 0) L.start_arr[c][ptr] = (uint8_t)pick;
+            if (lane0(lane)) L.start_arr[c][ptr] = (uint8_t)pick;
             wave_sync();
         }
         // weights + sort ascending by (int weight, segment) (align.cpp:492-495)
@@ -436,7 +466,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, bas
     }
     uint32_t n = st.nlog;
     if (n < cx.scratch_per_wave) {
-        if (lane == 0) {
+        if (lane0(lane)) {
             basal_hit h;
             h.loc = l; h.chr = chr; h.gap_size = (int8_t)gap_size; h.strand = (uint8_t)(((strand << 1) | chain) & 3);
             h.gap_pos = (uint16_t)gp; h.level = (uint8_t)w; h.chain = (uint8_t)chain; h.mode = (uint8_t)mode; h.pad = 0;
@@ -450,7 +480,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, bas
     uint32_t tot;
     {
         uint32_t a = L.nhit[chain][w] + 1u;
-        if (lane == 0) L.nhit[chain][w] = (uint16_t)a;
+        if (lane0(lane)) L.nhit[chain][w] = (uint16_t)a;
         tot = a + L.nhit[chain ^ 1][w];
     }
     wave_sync();
@@ -489,29 +519,45 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
     res.best_level = 0xFF;
     if (rd.len == 0 || rd.len > (uint32_t)NWT * 32 || rd.len > BASAL_MAXREADLEN) {
         res.status = BASAL_READ_SKIPPED;
-        if (lane == 0) cx.results[r] = res;
+        if (lane0(lane)) cx.results[r] = res;
         return;
     }
     ReadCtx rc;
-    uint32_t so[2];
     uint32_t slot = rd.readset == 2 ? 1 : 0;
-    so[0] = cx.carry[slot][0];
-    so[1] = cx.carry[slot][1];
-    if (rd.stale_src < cx.n) {  // inherit xseed_start_offset from an earlier read of this batch (align.cpp:475-480)
-        basal_read src = cx.reads[rd.stale_src];
-        prep_read<NWT>(cx, L, tab, src, rc, lane);
-        for (int c = 0; c < 2; c++)
-            if (rc.flag[c]) so[c] = best_start_offset<NWT>(cx, L, rc, c, lane, so[c]);
+    uint32_t so0 = cx.carry[slot][0], so1 = cx.carry[slot][1];
+    const bool stale = rd.stale_idx < cx.nstale;
+    if (stale) {  // inherit xseed_start_offset from an earlier read of this batch (align.cpp:475-480)
+        uint32_t srcno = cx.stales[rd.stale_idx].src;
+        if (srcno < r) {
+            basal_read src = cx.reads[srcno];
+            rc.rno = r;
+            prep_read<NWT>(cx, L, tab, src, rc, lane);
+            if (rc.on(0)) so0 = best_start_offset<NWT>(cx, L, rc, 0, lane, so0);
+            if (rc.on(1)) so1 = best_start_offset<NWT>(cx, L, rc, 1, lane, so1);
+        }
     }
+    rc.rno = r;
     prep_read<NWT>(cx, L, tab, rd, rc, lane);
-    for (int c = 0; c < 2; c++)
-        if (rc.flag[c] && rc.ii > 0) so[c] = best_start_offset<NWT>(cx, L, rc, c, lane, so[c]);
-    res.start_off[0] = (uint8_t)so[0];
-    res.start_off[1] = (uint8_t)so[1];
+    if (stale) {  // seed slots past this read's own seeds still hold an earlier read's values
+        if (lane < 30) {
+            uint32_t c = (uint32_t)lane / 15, j = (uint32_t)lane % 15, pos = rc.npos + j;
+            if (rc.on(c) && pos < (uint32_t)WaveLds<NWT>::MAXPOS) {
+                uint32_t sd = cx.stales[rd.stale_idx].overlay[c][j];
+                sd = (sd & 0x80000000u) | (uint32_t)guard_idx(cx, G_STALE, sd & 0x7fffffffu, cx.total_kmers, r);
+                L.seed[c][pos] = sd;
+                sd &= 0x7fffffffu;
+                L.cnt[c][pos] = cx.kmer_off[sd + 1] - cx.kmer_off[sd];
+            }
+        }
+        wave_sync();
+    }
+    if (rc.on(0) && rc.ii > 0) so0 = best_start_offset<NWT>(cx, L, rc, 0, lane, so0);
+    if (rc.on(1) && rc.ii > 0) so1 = best_start_offset<NWT>(cx, L, rc, 1, lane, so1);
+    res.start_off[0] = (uint8_t)so0;
+    res.start_off[1] = (uint8_t)so1;
     if (lane < 32) L.nhit[lane >> 4][lane & 15] = 0;
     wave_sync();
-    reorder_seed<NWT>(cx, L, rc, lane, so);
-
+    reorder_seed<NWT>(cx, L, rc, lane, so0, so1);
     HitState st;
     st.thr = rc.max_snp;
     st.nlog = 0;
@@ -525,11 +571,13 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
         uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0;
         if ((uint32_t)lane < nent) {
             uint32_t c = (uint32_t)lane / cx.I, i = (uint32_t)lane % cx.I;
-            if (rc.flag[c]) {
+            if (rc.on(c)) {
                 uint32_t seg = L.order[c][mode];
-                uint32_t pos = profile(seg, i, cx.K, cx.I) + L.start_arr[c][seg] - i;
+                uint32_t pos = profile(seg & 15, i, cx.K, cx.I) + L.start_arr[c][seg & 15] - i;
+                pos = (uint32_t)guard_idx(cx, G_LDSPOS, pos, WaveLds<NWT>::MAXPOS, r);
                 uint32_t sd = L.seed[c][pos] & 0x7fffffffu, m = L.cnt[c][pos];
-                if (m != 0 && m <= cx.max_kmer_num && pos < rc.npos) {
+                if (sd >= cx.total_kmers) sd = (uint32_t)guard_idx(cx, G_KMER2, 0x80000000u | pos | (seg << 16) | (c << 24) | (mode << 26), 0, r);
+                if (m != 0 && m <= cx.max_kmer_num) {
                     e_m = m;
                     e_off = cx.kmer_off[sd];
                     e_nfwd = cx.kmer_nfwd[sd];
@@ -562,7 +610,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
             if (active) {
                 uint32_t jj = e.jj0 + (t - e.pre);
                 if (jj >= e.m) jj -= e.m;
-                loc = cx.locs[e.off + jj] - e.h;
+                loc = cx.locs[guard_idx(cx, G_LOCS, (unsigned long long)e.off + jj, cx.nlocs, r)] - e.h;
+                if (((unsigned long long)(loc >> 5) + NWT + 4) >= cx.nwords) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
                 strand = jj >= e.nfwd;
                 uint32_t off2 = (loc & 31) * 2;
                 uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
@@ -573,7 +622,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
             bool gfound = false;
             uint32_t gsnp = 0, gpos = 0;
             int gshift = 0;
-            for (;;) {
+            for (uint32_t spin = 0;; spin++) {
+                if (spin > 2048) { guard_idx(cx, G_WATCHDOG, 0x10000u | spin, 0, r); done = true; break; }
                 if (GAP) {
                     bool mine = (gap_pending >> lane) & 1;
                     gfound = false;
@@ -638,7 +688,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
         if (cx.stream_mode == BASAL_STREAM_BEST || cx.stream_mode == BASAL_STREAM_ALL) {
             uint32_t need = cx.stream_mode == BASAL_STREAM_ALL ? st.nlog : sum;
             unsigned long long first = 0;
-            if (lane == 0) first = atomicAdd(cx.stream_used, (unsigned long long)need);
+            if (lane0(lane)) first = atomicAdd(cx.stream_used, (unsigned long long)need);
             first = ((unsigned long long)rfl((uint32_t)(first >> 32)) << 32) | rfl((uint32_t)first);
             res.stream_first = (uint32_t)first;
             res.stream_n = need;
@@ -665,7 +715,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
         // hits exist only above read_max_snp_num: cannot happen (levels are <= thr <= max_snp); kept for safety
         res.stream_n = 0;
     }
-    if (lane == 0) cx.results[r] = res;
+    if (lane0(lane)) cx.results[r] = res;
 }
 
 template <int NWT, bool NEWRULE, bool GAP>
@@ -682,11 +732,16 @@ __global__ __launch_bounds__(256) void align_kernel(DevCtx cx) {
     }
     wave_sync();
     basal_hit *log = cx.scratch + (size_t)(blockIdx.x * 4 + wv) * cx.scratch_per_wave;
-    for (;;) {
+    // every wave leaves this loop: the queue head only grows, and the iteration bound below is a
+    // watchdog against an internal error (a wave cannot legitimately take more than n reads)
+    for (uint32_t iter = 0;; iter++) {
+        // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
+        if (__ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(__ballot(1)), 0, iter); break; }
         uint32_t r = 0;
-        if (lane == 0) r = atomicAdd(cx.work_counter, 1u);
+        if (lane0(lane)) r = atomicAdd(cx.work_counter, 1u);
         r = rfl(r);
         if (r >= cx.n) break;
+        if (iter > cx.n) { guard_idx(cx, G_WATCHDOG, iter, 0, r); break; }
         process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, lane);
     }
 }
@@ -719,12 +774,13 @@ struct basal_core {
     // work buffers
     basal_hit *d_scratch = nullptr;
     uint32_t scratch_per_wave = 0;
-    unsigned int *d_counter = nullptr;
+    unsigned int *d_counter = nullptr;  // [0] work queue head, [1..24] guard ledger
     uint32_t grid = 0;
     int nwt = 0;
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; size_t cap_bases = 0;
     basal_read *d_reads = nullptr; size_t cap_reads = 0;
+    basal_stale *d_stales = nullptr; size_t cap_stales = 0;
     basal_result *d_results = nullptr;
     basal_hit *d_stream = nullptr; size_t cap_stream = 0;
     unsigned long long *d_used = nullptr;
@@ -765,7 +821,7 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
     memcpy(tabs + 768, p->alphabet_mread, 256);
     memcpy(tabs + 1024, p->rev_alphabet_mread, 256);
     HIP_TRY(hipMemcpy(c->d_tables, tabs, sizeof tabs, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&c->d_counter, sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&c->d_counter, 32 * sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&c->d_used, sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -781,7 +837,7 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipSetDevice(c->device);
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_tables); hipFree(c->d_scratch);
-    hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
+    hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -887,7 +943,8 @@ extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_
 }
 
 // max_len: the longest read of the batch, selects the kernel instantiation
-static int launch_align(basal_core *c, const void *d_bases, const void *d_reads, uint32_t n, uint32_t max_len, int stream_mode, void *d_results,
+static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale, uint32_t max_len,
+                        int stream_mode, void *d_results,
                         void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2], hipStream_t s) {
     if (!c->have_ref || !c->have_index) { g_err = "align: reference/index not staged (call set_reference and set_index/build_index first)"; return BASAL_ESTATE; }
     if (stream_mode < 0 || stream_mode > 2) { g_err = "align: bad stream_mode"; return BASAL_EINVAL; }
@@ -904,6 +961,7 @@ static int launch_align(basal_core *c, const void *d_bases, const void *d_reads,
     cx.randseed = c->p.randseed; cx.gap = c->p.gap; cx.gap_edge = c->p.gap_edge; cx.n_mis = c->p.n_mis;
     cx.stream_mode = (uint32_t)stream_mode; cx.report_repeat_hits = c->p.report_repeat_hits;
     cx.tables = c->d_tables; cx.bases = (const uint8_t *)d_bases; cx.reads = (const basal_read *)d_reads; cx.n = n;
+    cx.stales = (const basal_stale *)d_stales; cx.nstale = d_stales ? nstale : 0;
     cx.results = (basal_result *)d_results; cx.stream = (basal_hit *)d_stream; cx.stream_cap = stream_cap;
     cx.stream_used = (unsigned long long *)d_stream_used;
     cx.scratch = c->d_scratch; cx.scratch_per_wave = c->scratch_per_wave; cx.work_counter = c->d_counter;
@@ -912,26 +970,38 @@ static int launch_align(basal_core *c, const void *d_bases, const void *d_reads,
     c->nwt = nwt;
     bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
     kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp) : nwt == 8 ? pick_kernel<8>(nr, gp) : pick_kernel<16>(nr, gp);
-    HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned int), s));
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 32 * sizeof(unsigned int), s));
+    cx.guard = c->d_counter + 1;
+    cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
     uint32_t grid = c->grid;
     uint32_t need = (n + 3) / 4;
     if (grid > need) grid = need;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
+    static const bool dbg = getenv("BASAL_DEBUG") != nullptr;
+    if (dbg) {
+        HIP_TRY(hipStreamSynchronize(s));
+        fprintf(stderr, "[basal debug] launching align kernel NWT=%d newrule=%d gap=%d grid=%u n=%u nstale=%u max_kmer_num=%u nlocs=%llu\n", nwt, (int)nr,
+                (int)gp, grid, n, cx.nstale, cx.max_kmer_num, (unsigned long long)c->nlocs);
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, cx);
     HIP_TRY(hipGetLastError());
+    if (dbg) {
+        HIP_TRY(hipStreamSynchronize(s));
+        fprintf(stderr, "[basal debug] align kernel finished\n");
+    }
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, s)); c->timed = true; }
     return BASAL_OK;
 }
 
-extern "C" int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const void *d_reads, uint32_t n, int stream_mode, void *d_results,
-                                             void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2], uint32_t max_len,
-                                             void *hip_stream) {
+extern "C" int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
+                                             int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used,
+                                             const uint8_t carry[2][2], uint32_t max_len, void *hip_stream) {
     if (!c || (n && (!d_bases || !d_reads || !d_results))) { g_err = "align_batch_device: null argument"; return BASAL_EINVAL; }
     if (max_len == 0 || max_len > BASAL_MAXREADLEN) { g_err = "align_batch_device: max_len must be 1..480"; return BASAL_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
-    return launch_align(c, d_bases, d_reads, n, max_len, stream_mode, d_results, d_stream, stream_cap, d_stream_used, carry ? carry : zero_carry,
-                        (hipStream_t)hip_stream);
+    return launch_align(c, d_bases, ~0ull, d_reads, n, d_stales, nstale, max_len, stream_mode, d_results, d_stream, stream_cap, d_stream_used,
+                        carry ? carry : zero_carry, (hipStream_t)hip_stream);
 }
 
 template <typename T>
@@ -945,8 +1015,9 @@ static int grow(T *&p, size_t &cap, size_t need) {
     return BASAL_OK;
 }
 
-extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, int stream_mode,
-                                      basal_result *results, basal_hit *stream, uint64_t stream_cap, uint64_t *stream_used, uint8_t carry[2][2]) {
+extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, const basal_stale *stales,
+                                      uint32_t nstale, int stream_mode, basal_result *results, basal_hit *stream, uint64_t stream_cap,
+                                      uint64_t *stream_used, uint8_t carry[2][2]) {
     if (!c || (n && (!bases || !reads || !results))) { g_err = "align_batch: null argument"; return BASAL_EINVAL; }
     if (stream_mode != BASAL_STREAM_NONE && (!stream || !stream_used)) { g_err = "align_batch: stream buffers required for this stream_mode"; return BASAL_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
@@ -959,9 +1030,10 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
         if (r.len == 0) continue;
         if (r.len > BASAL_MAXREADLEN || (uint64_t)r.seq_off + r.len > nbases) { g_err = "align_batch: read descriptor out of range"; return BASAL_EINVAL; }
         if (r.max_snp > BASAL_MAXSNPS) { g_err = "align_batch: max_snp > 15"; return BASAL_EINVAL; }
-        if (r.stale_src < n) {
-            const basal_read &s = reads[r.stale_src];
-            if (r.stale_src >= i || s.len == 0 || s.len < K + I - 1) { g_err = "align_batch: stale_src must name an earlier aligned read"; return BASAL_EINVAL; }
+        if (r.stale_idx != BASAL_STALE_NONE) {
+            if (!stales || r.stale_idx >= nstale) { g_err = "align_batch: stale_idx outside the stale table"; return BASAL_EINVAL; }
+            uint32_t src = stales[r.stale_idx].src;
+            if (src != BASAL_STALE_CARRY && (src >= i || reads[src].len < K + I - 1)) { g_err = "align_batch: basal_stale.src must name an earlier aligned read"; return BASAL_EINVAL; }
         }
         if (r.len > max_len) max_len = r.len;
     }
@@ -973,6 +1045,7 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
         c->d_results = nullptr;
     }
     if ((rc = grow(c->d_reads, c->cap_reads, n))) return rc;
+    if (nstale && (rc = grow(c->d_stales, c->cap_stales, nstale))) return rc;
     if (!c->d_results) HIP_TRY(hipMalloc(&c->d_results, c->cap_reads * sizeof(basal_result)));
     (void)cap_res;
     if (stream_mode != BASAL_STREAM_NONE)
@@ -980,15 +1053,25 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_bases, bases, nbases, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
+    if (nstale) HIP_TRY(hipMemcpyAsync(c->d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(c->d_used, 0, sizeof(unsigned long long), s));
     static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
-    rc = launch_align(c, c->d_bases, c->d_reads, n, max_len, stream_mode, c->d_results, c->d_stream, stream_cap, c->d_used,
+    rc = launch_align(c, c->d_bases, nbases, c->d_reads, n, nstale ? c->d_stales : nullptr, nstale, max_len, stream_mode, c->d_results, c->d_stream, stream_cap, c->d_used,
                       carry ? (const uint8_t(*)[2])carry : zero_carry, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(results, c->d_results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, s));
     unsigned long long used = 0;
+    unsigned int guard[24];
     HIP_TRY(hipMemcpyAsync(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(guard, c->d_counter + 1, sizeof guard, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 8; k++)
+        if (guard[k]) {
+            static const char *kind[8] = {"k-mer id", "location-list index", "reference word", "base offset", "seed slot", "stale overlay k-mer", "k-mer id of a mode seed (value = pos|seg<<16|chain<<24|mode<<26)", "watchdog (a loop did not terminate)"};
+            g_err = std::string("align_batch: internal bounds violation (") + kind[k] + "): " + std::to_string(guard[k]) + " times, first value " +
+                    std::to_string(guard[8 + k]) + " at read " + std::to_string(guard[16 + k]);
+            return BASAL_EDEVICE;
+        }
     if (stream_used) *stream_used = used;
     int ret = BASAL_OK;
     if (stream_mode != BASAL_STREAM_NONE) {

@@ -448,6 +448,64 @@ extern "C" int basal_host_filter_read(const basal_params *p, char *seq, char *qu
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ inherited state
+
+struct basal_stale_tracker {
+    basal_params p;
+    struct Owner { uint32_t npos; std::string seq; };
+    struct Slot {
+        uint32_t last_def = BASAL_STALE_CARRY;  // most recent read of this batch that defined the start offset
+        std::vector<Owner> stack;               // most recent on top; npos strictly increasing towards the bottom
+    } slot[2];
+};
+
+extern "C" basal_stale_tracker_t *basal_host_stale_new(const basal_params *p) {
+    basal_stale_tracker *t = new basal_stale_tracker();
+    t->p = *p;
+    return t;
+}
+extern "C" void basal_host_stale_free(basal_stale_tracker_t *t) { delete t; }
+extern "C" void basal_host_stale_begin_batch(basal_stale_tracker_t *t) { t->slot[0].last_def = t->slot[1].last_def = BASAL_STALE_CARRY; }
+
+// seed (xseed_array) and N flag (xseedreg_array) of `seq` at read offset pos on chain c (align.cpp:92-100)
+static uint32_t host_seed_at(const basal_params &p, const std::string &seq, uint32_t pos, int c) {
+    const uint32_t K = p.seed_size, L = (uint32_t)seq.size();
+    uint32_t s = 0;
+    bool n = false;
+    for (uint32_t t = 0; t < K; t++) {
+        unsigned char ch = (unsigned char)(c ? seq[L - 1 - (pos + t)] : seq[pos + t]);
+        s = (s << 2) | (c ? p.rev_alphabet[ch] : p.alphabet[ch]);
+        n |= !p.reg_alphabet[ch];
+    }
+    return XT(s) | (n ? 0x80000000u : 0);
+}
+
+extern "C" int basal_host_stale_visit(basal_stale_tracker_t *t, const char *seq, uint32_t len, uint32_t readset, int qc_failed,
+                                      uint32_t read_number_in_batch, basal_stale *out) {
+    if (qc_failed || len == 0) return 0;  // FilterReads failed: RunAlign never ran, nothing was written
+    const basal_params &p = t->p;
+    basal_stale_tracker::Slot &S = t->slot[readset == 2 ? 1 : 0];
+    const uint32_t K = p.seed_size, I = p.index_interval;
+    const uint32_t npos = len >= K ? len - K + 1 : 0;
+    const bool flag[2] = {(p.chains == 1) || ((p.chains <= 1) == (readset < 2)), (p.chains == 1) || ((p.chains <= 1) == (readset == 2))};
+    int stale = 0;
+    if ((len - I + 1) % K == 0) {
+        stale = 1;
+        out->src = S.last_def;
+        for (int c = 0; c < 2; c++)
+            for (uint32_t j = 0; j < 15; j++) {
+                uint32_t pos = npos + j, v = 0;  // never-written slots hold 0 (a fresh SingleAlign object)
+                if (flag[c])
+                    for (size_t k = S.stack.size(); k-- > 0;)
+                        if (S.stack[k].npos > pos) { v = host_seed_at(p, S.stack[k].seq, pos, c); break; }
+                out->overlay[c][j] = v;
+            }
+    } else S.last_def = read_number_in_batch;
+    while (!S.stack.empty() && S.stack.back().npos <= npos) S.stack.pop_back();
+    S.stack.push_back({npos, std::string(seq, len)});
+    return stale;
+}
+
 // ------------------------------------------------------------------------------------------ SAM
 
 namespace {

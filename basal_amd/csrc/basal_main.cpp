@@ -222,6 +222,8 @@ int main(int argc, char **argv) {
         std::vector<basal_read> descs;
         std::vector<basal_result> results;
         std::vector<basal_hit> stream;
+        std::vector<basal_stale> stales;
+        basal_stale_tracker_t *tracker = basal_host_stale_new(&P);
         const int smode = P.report_repeat_hits == 2 ? BASAL_STREAM_BEST : BASAL_STREAM_NONE;
         while (load_batch(ra, P, read_end, batch, 0, recs)) {
             double h0 = now();
@@ -231,20 +233,24 @@ int main(int argc, char **argv) {
             });
             descs.assign(n, basal_read{});
             bases.clear();
-            uint32_t last_def = BASAL_STALE_CARRY;  // most recent read that leaves xseed_start_offset defined
+            stales.clear();
+            basal_host_stale_begin_batch(tracker);
             for (size_t i = 0; i < n; i++) {
                 basal_read &d = descs[i];
                 d.index = recs[i].index;
                 d.readset = 0;
-                d.stale_src = BASAL_STALE_NONE;
+                d.stale_idx = BASAL_STALE_NONE;
                 if (recs[i].qc_failed) { d.len = 0; continue; }
                 uint32_t len = (uint32_t)strlen(recs[i].seq.data());
                 d.len = (uint16_t)len;
                 d.max_snp = (uint8_t)recs[i].max_snp;
                 d.seq_off = (uint32_t)bases.size();
                 bases.insert(bases.end(), recs[i].seq.begin(), recs[i].seq.begin() + len);
-                if ((len - P.index_interval + 1) % P.seed_size == 0) d.stale_src = last_def;
-                else last_def = (uint32_t)i;
+                basal_stale se;
+                if (basal_host_stale_visit(tracker, recs[i].seq.data(), len, 0, 0, (uint32_t)i, &se)) {
+                    d.stale_idx = (uint32_t)stales.size();
+                    stales.push_back(se);
+                }
             }
             results.assign(n, basal_result{});
             uint64_t cap = smode ? (uint64_t)n * 4 + 1024 : 0, used = 0;
@@ -253,7 +259,7 @@ int main(int argc, char **argv) {
                 stream.resize(cap ? cap : 1);
                 uint8_t cy[2][2];
                 memcpy(cy, carry, 4);
-                int rc = basal_core_align_batch(core, bases.data(), bases.size(), descs.data(), (uint32_t)n, smode, results.data(), stream.data(), cap, &used, cy);
+                int rc = basal_core_align_batch(core, bases.data(), bases.size(), descs.data(), (uint32_t)n, stales.data(), (uint32_t)stales.size(), smode, results.data(), stream.data(), cap, &used, cy);
                 if (rc == BASAL_EOVERFLOW) { cap = used + 1024; continue; }
                 if (rc) die(std::string("align_batch: ") + basal_last_error());
                 memcpy(carry, cy, 4);

@@ -108,11 +108,21 @@ typedef struct basal_read {
     uint16_t len;       /* 0: skip */
     uint8_t readset;    /* 0 SE, 1 mate 1, 2 mate 2 */
     uint8_t max_snp;    /* read_max_snp_num */
-    uint32_t stale_src; /* where xseed_start_offset comes from when (len-I+1)%k==0:
-                           BASAL_STALE_NONE, BASAL_STALE_CARRY, or a read number in this batch */
+    uint32_t stale_idx; /* BASAL_STALE_NONE, or this read's entry in the batch's basal_stale table */
 } basal_read;
 #define BASAL_STALE_NONE 0xFFFFFFFFu
 #define BASAL_STALE_CARRY 0xFFFFFFFEu
+
+/* State a read inherits from EARLIER reads of the same SingleAlign object. The reference keeps
+ * xseed_start_offset and xseed_array as members that a read with (len-I+1)%k==0 does not rewrite
+ * (align.cpp:475-480): such a read reuses the previous start offset and, through it, may index
+ * seed slots beyond its own length that still hold an earlier, longer read's seeds. Reproducing
+ * `-p 1` output bit for bit needs both; basal_host_stale_* computes this table on the host. */
+typedef struct basal_stale {
+    uint32_t src;             /* read number in this batch whose start offset is inherited, or BASAL_STALE_CARRY */
+    uint32_t overlay[2][15];  /* [chain][j]: xseed_array[chain][npos+j] as left by earlier reads: 3-letter seed
+                                 hash, bit 31 = window held a non-ACGT base; npos = len-k+1 of this read */
+} basal_stale;
 
 /* what goes into the hit stream */
 #define BASAL_STREAM_NONE 0 /* -r 0/1 SE: basal_result.best is enough */
@@ -147,17 +157,18 @@ int basal_core_get_index(basal_core_t *c, uint32_t *kmer_off, uint32_t *kmer_nfw
  * batch (slot 0: SE reads and mate 1, slot 1: mate 2); updated on return.
  * stream may be NULL when stream_mode==BASAL_STREAM_NONE. */
 int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n,
-                           int stream_mode, basal_result *results, basal_hit *stream, uint64_t stream_cap,
-                           uint64_t *stream_used, uint8_t carry[2][2]);
+                           const basal_stale *stales, uint32_t nstale, int stream_mode, basal_result *results,
+                           basal_hit *stream, uint64_t stream_cap, uint64_t *stream_used, uint8_t carry[2][2]);
 
 /* Same, but every buffer is already resident in HBM (device pointers) and the work is queued on
  * `stream` (a hipStream_t passed as void*, NULL = the null stream) without synchronising.
  * d_stream_used: device uint64 counter, must be zero on entry. max_len: an upper bound of the read
  * lengths in the batch (<=480); it selects the kernel instantiation (reads longer than it are skipped).  This is the entry point the
  * benchmark times and the one a multi-GPU driver uses before its RCCL gather of results. */
-int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const void *d_reads, uint32_t n, int stream_mode,
-                                  void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used,
-                                  const uint8_t carry[2][2], uint32_t max_len, void *hip_stream);
+int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const void *d_reads, uint32_t n,
+                                  const void *d_stales, uint32_t nstale, int stream_mode, void *d_results,
+                                  void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2],
+                                  uint32_t max_len, void *hip_stream);
 
 /* Kernel-time instrumentation: milliseconds of the last align_batch* kernel measured with HIP
  * events on the stream it ran on (0 if timing is off). */
@@ -199,6 +210,17 @@ uint64_t basal_host_ref_nlocs(const basal_ref_t *r);
 uint32_t basal_host_ref_max_kmer_num(const basal_ref_t *r);
 /* convenience: set_reference + (set_index | build_index) */
 int basal_host_ref_upload(const basal_ref_t *r, basal_core_t *c, int build_index_on_gpu, uint32_t *max_kmer_num);
+
+/* Tracks, per SingleAlign object (slot 0: SE reads and mate 1; slot 1: mate 2), what later reads can
+ * inherit (see basal_stale). Call begin_batch at the start of every batch, then visit every read of
+ * the batch in input order (QC-failed ones too, with qc_failed=1). visit returns 1 and fills *out
+ * when the read needs a basal_stale entry (its descriptor's stale_idx must then point at it), else 0. */
+typedef struct basal_stale_tracker basal_stale_tracker_t;
+basal_stale_tracker_t *basal_host_stale_new(const basal_params *p);
+void basal_host_stale_free(basal_stale_tracker_t *t);
+void basal_host_stale_begin_batch(basal_stale_tracker_t *t);
+int basal_host_stale_visit(basal_stale_tracker_t *t, const char *seq, uint32_t len, uint32_t readset, int qc_failed,
+                           uint32_t read_number_in_batch, basal_stale *out);
 
 /* FilterReads (align.cpp:548-563): trims seq/qual in place (NUL-terminated, caller-owned,
  * qual buffer at least as long as seq), returns 1 if the read fails QC, else 0 with

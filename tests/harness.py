@@ -48,29 +48,43 @@ def filter_reads(params, reads, readset=0, first_index=0):
     return out
 
 
-def make_batch(params, recs):
-    """(bases, descriptors) for basal_core_align_batch, with the stale_src chain per aligner slot."""
+class StaleTracker:
+    """basal_host_stale_* (the host-side tracker of state inherited between reads)."""
+
+    def __init__(self, params):
+        self.h = B.lib().basal_host_stale_new(C.byref(params.c))
+
+    def __del__(self):
+        try:
+            B.lib().basal_host_stale_free(self.h)
+        except Exception:
+            pass
+
+
+def make_batch(params, recs, tracker=None):
+    """(bases, descriptors, stale table) for basal_core_align_batch."""
+    L = B.lib()
+    tracker = tracker or StaleTracker(params)
+    L.basal_host_stale_begin_batch(tracker.h)
     descs = np.zeros(len(recs), bc.READ_DTYPE)
-    chunks = []
+    chunks, stales = [], []
     off = 0
-    last_def = {0: B.STALE_CARRY, 1: B.STALE_CARRY}
-    K, I = params.c.seed_size, params.c.index_interval
     for i, r in enumerate(recs):
         d = descs[i]
-        d["index"], d["readset"], d["stale_src"] = r["index"], r["readset"], B.STALE_NONE
+        d["index"], d["readset"], d["stale_idx"] = r["index"], r["readset"], B.STALE_NONE
         if r["qc"]:
             continue
         n = len(r["seq"])
         d["len"], d["max_snp"], d["seq_off"] = n, r["max_snp"], off
         chunks.append(np.frombuffer(r["seq"].encode(), np.uint8))
         off += n
-        slot = 1 if r["readset"] == 2 else 0
-        if (n - I + 1) % K == 0:
-            d["stale_src"] = last_def[slot]
-        else:
-            last_def[slot] = i
+        se = bc.basal_stale()
+        if L.basal_host_stale_visit(tracker.h, r["seq"].encode(), n, r["readset"], 0, i, C.byref(se)):
+            d["stale_idx"] = len(stales)
+            stales.append(np.frombuffer(bytes(se), bc.STALE_DTYPE)[0])
     bases = np.concatenate(chunks) if chunks else np.zeros(1, np.uint8)
-    return bases, descs
+    st = np.array(stales, dtype=bc.STALE_DTYPE) if stales else np.zeros(0, bc.STALE_DTYPE)
+    return bases, descs, st
 
 
 def format_se(params, ref, recs, results, stream):

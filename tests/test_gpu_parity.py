@@ -25,12 +25,13 @@ def run_product(name, stream_mode, extra_flags=(), batch=None):
     recs = H.filter_reads(p, reads)
     results, streams = [], []
     carry = None
+    tracker = H.StaleTracker(p)
     step = batch or len(recs)
     all_stream = []
     for b0 in range(0, len(recs), step):
         part = recs[b0:b0 + step]
-        bases, descs = H.make_batch(p, part)
-        res, stream, carry = core.align_batch(bases, descs, stream_mode, stream_cap=200000, carry=carry)
+        bases, descs, stales = H.make_batch(p, part, tracker)
+        res, stream, carry = core.align_batch(bases, descs, stream_mode, stream_cap=200000, carry=carry, stales=stales)
         res = res.copy()
         res["stream_first"] += len(all_stream)
         results.append(res)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Static check of the gfx950 ISA of the HIP core (no GPU needed).
+
+Compiles basal_core.hip to assembly and fails if a kernel contains a label whose next instructions
+branch straight back to it on a loop-invariant condition: that shape is what hipcc (ROCm 7.2)
+emitted when jump threading split lane 0 from lanes 1..63 across the persistent work loop (see
+lane0() in basal_core.hip) -- on the GPU it showed up as a hang or as reads aligned by a partial
+wave.  Also reports VGPR/SGPR-spill/scratch/LDS use per kernel.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "basal_amd", "csrc", "basal_core.hip")
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "core.s")
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-S",
+                            "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", SRC, "-o", out], capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr)
+            return 2
+        lines = open(out).read().split("\n")
+    bad = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m:
+            continue
+        lab = re.escape(m.group(1))
+        for j in range(i + 1, min(i + 4, len(lines))):
+            if re.search(r"s_c?branch\w*\s+" + lab + r"\s*$", lines[j]):
+                print("self-loop at asm line %d: %s" % (i + 1, m.group(1)))
+                bad += 1
+                break
+    name = None
+    for l in r.stderr.split("\n"):
+        m = re.search(r"Function Name: (\S+)", l)
+        if m:
+            name = m.group(1)
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\d+)", l)
+        if m and name:
+            print("%-60s %-28s %s" % (name[-60:], m.group(1), m.group(2)))
+    if re.search(r"\bflat_(load|store)", "\n".join(lines)):
+        print("flat_* memory instructions present (LDS/global address space not resolved)")
+        bad += 1
+    print("ISA check: %s" % ("FAILED" if bad else "ok"))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
