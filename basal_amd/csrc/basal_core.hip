@@ -26,6 +26,7 @@
 #include "../../include/basal_core.h"
 #include "basal_bits.h"
 #include "basal_internal.h"
+#include "basal_core_priv.h"
 
 using namespace basal;
 
@@ -757,37 +758,6 @@ kernel_fn pick_kernel(bool newrule, bool gap) {
 
 // ------------------------------------------------------------------------------------------------
 // host side of the core
-struct basal_core {
-    basal_params p;
-    int device = 0;
-    hipDeviceProp_t prop;
-    // reference + index in HBM
-    uint64_t *d_xref[2] = {nullptr, nullptr};
-    uint64_t nwords = 0;
-    uint32_t *d_anchor = nullptr, *d_size = nullptr, *d_rcoff = nullptr;
-    uint32_t ncontig = 0;
-    uint32_t *d_koff = nullptr, *d_knfwd = nullptr, *d_locs = nullptr;
-    uint64_t nlocs = 0;
-    uint32_t total_kmers = 0, max_kmer_num = 0;
-    bool have_ref = false, have_index = false;
-    uint8_t *d_tables = nullptr;
-    // work buffers
-    basal_hit *d_scratch = nullptr;
-    uint32_t scratch_per_wave = 0;
-    unsigned int *d_counter = nullptr;  // [0] work queue head, [1..24] guard ledger
-    uint32_t grid = 0;
-    int nwt = 0;
-    // staging for the host-buffer entry point
-    uint8_t *d_bases = nullptr; size_t cap_bases = 0;
-    basal_read *d_reads = nullptr; size_t cap_reads = 0;
-    basal_stale *d_stales = nullptr; size_t cap_stales = 0;
-    basal_result *d_results = nullptr;
-    basal_hit *d_stream = nullptr; size_t cap_stream = 0;
-    unsigned long long *d_used = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timing = false, timed = false;
-};
 
 extern "C" const char *basal_last_error(void) { return g_err.c_str(); }
 namespace basal { void set_error(const std::string &s) { g_err = s; } }
@@ -1096,10 +1066,4 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
         }
     }
     return ret;
-}
-
-extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, uint64_t nblocks, uint32_t *max_kmer_num_out) {
-    (void)c; (void)blocks; (void)nblocks; (void)max_kmer_num_out;
-    g_err = "build_index: GPU index build not implemented yet";
-    return BASAL_ESTATE;
 }

@@ -1,0 +1,37 @@
+// basal_core_priv.h -- the core object shared by the HIP translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/basal_core.h"
+
+struct basal_core {
+    basal_params p;
+    int device = 0;
+    hipDeviceProp_t prop;
+    // reference + index in HBM
+    uint64_t *d_xref[2] = {nullptr, nullptr};
+    uint64_t nwords = 0;
+    uint32_t *d_anchor = nullptr, *d_size = nullptr, *d_rcoff = nullptr;
+    uint32_t ncontig = 0;
+    uint32_t *d_koff = nullptr, *d_knfwd = nullptr, *d_locs = nullptr;
+    uint64_t nlocs = 0;
+    uint32_t total_kmers = 0, max_kmer_num = 0;
+    bool have_ref = false, have_index = false;
+    uint8_t *d_tables = nullptr;
+    // work buffers
+    basal_hit *d_scratch = nullptr;
+    uint32_t scratch_per_wave = 0;
+    unsigned int *d_counter = nullptr;  // [0] work queue head, [1..24] guard ledger
+    uint32_t grid = 0;
+    int nwt = 0;
+    // staging for the host-buffer entry point
+    uint8_t *d_bases = nullptr; size_t cap_bases = 0;
+    basal_read *d_reads = nullptr; size_t cap_reads = 0;
+    basal_stale *d_stales = nullptr; size_t cap_stales = 0;
+    basal_result *d_results = nullptr;
+    basal_hit *d_stream = nullptr; size_t cap_stream = 0;
+    unsigned long long *d_used = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false, timed = false;
+};

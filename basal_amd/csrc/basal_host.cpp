@@ -302,11 +302,13 @@ static inline uint32_t seed_at(const uint64_t *m, uint32_t pos, uint32_t K) {
 
 // The over-represented k-mer cut-off (refbase.cpp:362-363): element [(u32)(total*(1-ratio)) - 1] of
 // the counts after sorting all but the LAST k-mer id ascending; the product is single precision.
-uint32_t basal_kmer_cutoff_index(uint32_t total_kmers, float ratio) {
+namespace basal {
+uint32_t kmer_cutoff_index(uint32_t total_kmers, float ratio) {
     volatile float one_minus = 1 - ratio;
     volatile float prod = (float)total_kmers * one_minus;
     return (uint32_t)prod - 1;
 }
+}  // namespace basal
 
 extern "C" int basal_host_ref_build_index(basal_ref_t *r, const basal_params *p, int threads) {
     if (!r || !p) { set_error("build_index: null argument"); return BASAL_EINVAL; }
@@ -361,7 +363,7 @@ extern "C" int basal_host_ref_build_index(basal_ref_t *r, const basal_params *p,
     }
     r->kmer_nfwd.swap(cf);
     // cut-off: order statistic over ids 0..total-2 via a histogram of counts
-    uint32_t idx = basal_kmer_cutoff_index(total, p->max_kmer_ratio);
+    uint32_t idx = kmer_cutoff_index(total, p->max_kmer_ratio);
     if (idx >= total - 1) r->max_kmer_num = r->kmer_off[total] - r->kmer_off[total - 1];
     else {
         uint32_t mx = 0;

@@ -1,0 +1,178 @@
+// basal_index.hip -- the seed index built on the GPU (RefSeq::CreateIndex, refbase.cpp:261-439).
+//
+// The reference counts k-mers, allocates 16-byte headers and fills per-k-mer lists with two
+// threads (forward / reverse strand). Here the same table -- per 3-letter k-mer: forward entries
+// ascending, then reverse-complement entries ascending, as global coordinates -- is produced as
+//   1. one (key = 2*kmer + strand, value = global coordinate) pair per indexed position, emitted in
+//      block order (which is ascending coordinate order within a strand) while the keys are
+//      counted with atomics;
+//   2. an exclusive scan of the counts = CSR offsets;
+//   3. a STABLE radix sort of the pairs by key, so equal keys keep ascending coordinates.
+// It is HBM-bound streaming work (8 B written + read per pass and pair), not a GEMM.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "basal_bits.h"
+#include "basal_core_priv.h"
+#include "basal_internal.h"
+
+using namespace basal;
+
+namespace {
+
+#define HIP_TRYI(x)                                                         \
+    do {                                                                    \
+        hipError_t e_ = (x);                                                \
+        if (e_ != hipSuccess) {                                             \
+            set_error(std::string(#x) + ": " + hipGetErrorString(e_));      \
+            return BASAL_EDEVICE;                                           \
+        }                                                                   \
+    } while (0)
+
+struct BlockDesc {  // one unmasked block of one strand (RefSeq::_blocks) prepared for the device
+    unsigned long long first;  // index of its first indexed position in the global enumeration
+    unsigned long long word_base;  // first 64-bit word of its contig inside xref
+    uint32_t i0, strand, anchor, pad;
+};
+
+// one thread per indexed position: hash the k-mer, count the key, emit the pair
+__global__ __launch_bounds__(256) void emit_pairs(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const BlockDesc *__restrict__ blk,
+                                                  uint32_t nblk, unsigned long long npos, uint32_t K, uint32_t I, uint32_t *__restrict__ keys,
+                                                  uint32_t *__restrict__ vals, uint32_t *__restrict__ cnt) {
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < npos; t += (unsigned long long)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = nblk;  // last block with first <= t
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (blk[mid].first <= t) lo = mid;
+            else hi = mid;
+        }
+        const BlockDesc b = blk[lo];
+        uint32_t pos = b.i0 + (uint32_t)(t - b.first) * I;
+        const uint64_t *w = (b.strand ? xr : xf) + b.word_base + (pos >> 5);
+        uint32_t a = (pos & 31) * 2;
+        uint64_t v = a ? (w[0] << a) | (w[1] >> (64 - a)) : w[0];  // s_MakeSeed_1, refbase.cpp:254-255
+        uint32_t key = XT((uint32_t)(v >> (64 - 2 * K))) * 2 + b.strand;
+        keys[t] = key;
+        vals[t] = b.anchor + pos;  // hit2int, refbase.cpp:485-487
+        atomicAdd(&cnt[key], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void split_counts(const uint32_t *__restrict__ off2, const uint32_t *__restrict__ cnt2, uint32_t total_kmers,
+                                                    uint32_t nlocs, uint32_t *__restrict__ koff, uint32_t *__restrict__ knfwd) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < total_kmers) {
+        koff[k] = off2[2 * k];
+        knfwd[k] = cnt2[2 * k];
+    } else if (k == total_kmers) koff[k] = nlocs;
+}
+
+}  // namespace
+
+extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, uint64_t nblocks, uint32_t *max_kmer_num_out) {
+    if (!c || (!blocks && nblocks)) { set_error("build_index: null argument"); return BASAL_EINVAL; }
+    if (!c->have_ref) { set_error("build_index: stage the reference first (basal_core_set_reference)"); return BASAL_ESTATE; }
+    HIP_TRYI(hipSetDevice(c->device));
+    const uint32_t K = c->p.seed_size, I = c->p.index_interval, total = c->total_kmers;
+    // contig word bases and anchors come from the staged reference
+    std::vector<uint32_t> anchor(c->ncontig + 1);
+    HIP_TRYI(hipMemcpy(anchor.data(), c->d_anchor, (c->ncontig + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<BlockDesc> bd;
+    unsigned long long npos = 0;
+    for (uint64_t b = 0; b < nblocks; b++) {
+        uint32_t id = blocks[3 * b], beg = blocks[3 * b + 1], end = blocks[3 * b + 2];
+        if ((id >> 1) >= c->ncontig || end < beg) { set_error("build_index: bad block (contig not staged, or end < begin)"); return BASAL_EINVAL; }
+        if (end < K) continue;
+        uint32_t i0 = (beg / I) * I, i2 = ((end - K) / I) * I;  // refbase.cpp:310-316
+        if (i2 < i0) continue;
+        BlockDesc d;
+        d.first = npos;
+        d.word_base = anchor[id >> 1] / 32;
+        d.i0 = i0;
+        d.strand = id & 1;
+        d.anchor = anchor[id >> 1];
+        d.pad = 0;
+        bd.push_back(d);
+        npos += (i2 - i0) / I + 1;
+    }
+    if (npos >= 0xFFFFFFFFull) { set_error("build_index: more than 2^32-1 index entries"); return BASAL_EINVAL; }
+    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs);
+    c->d_koff = c->d_knfwd = c->d_locs = nullptr;
+    c->have_index = false;
+    uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr, *d_cnt = nullptr, *d_off2 = nullptr;
+    BlockDesc *d_blk = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() { hipFree(d_keys); hipFree(d_keys2); hipFree(d_vals); hipFree(d_vals2); hipFree(d_cnt); hipFree(d_off2); hipFree(d_blk); hipFree(d_tmp); };
+#define TRYC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); cleanup(); return BASAL_EDEVICE; } } while (0)
+    const size_t nkeys = (size_t)total * 2;
+    TRYC(hipMalloc(&d_cnt, nkeys * 4));
+    TRYC(hipMalloc(&d_off2, nkeys * 4));
+    TRYC(hipMemset(d_cnt, 0, nkeys * 4));
+    TRYC(hipMalloc(&c->d_koff, ((size_t)total + 1) * 4));
+    TRYC(hipMalloc(&c->d_knfwd, (size_t)total * 4));
+    TRYC(hipMalloc(&d_vals2, (npos + 64) * 4));  // becomes locs
+    if (npos) {
+        TRYC(hipMalloc(&d_keys, npos * 4));
+        TRYC(hipMalloc(&d_keys2, npos * 4));
+        TRYC(hipMalloc(&d_vals, npos * 4));
+        TRYC(hipMalloc(&d_blk, bd.size() * sizeof(BlockDesc)));
+        TRYC(hipMemcpy(d_blk, bd.data(), bd.size() * sizeof(BlockDesc), hipMemcpyHostToDevice));
+        unsigned long long want = (npos + 255) / 256;
+        uint32_t grid = (uint32_t)std::min<unsigned long long>(want, (unsigned long long)c->prop.multiProcessorCount * 32);
+        hipLaunchKernelGGL(emit_pairs, dim3(grid), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], d_blk, (uint32_t)bd.size(), npos, K, I, d_keys, d_vals, d_cnt);
+        TRYC(hipGetLastError());
+    }
+    size_t tmp_bytes = 0, tmp2 = 0;
+    TRYC(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_off2, (int)nkeys));
+    if (npos) {
+        int end_bit = 1;
+        while ((1ull << end_bit) < nkeys) end_bit++;
+        TRYC(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, d_keys, d_keys2, d_vals, d_vals2, (int)npos, 0, end_bit));
+        tmp_bytes = std::max(tmp_bytes, tmp2);
+    }
+    TRYC(hipMalloc(&d_tmp, tmp_bytes + 256));
+    TRYC(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_off2, (int)nkeys));
+    if (npos) {
+        int end_bit = 1;
+        while ((1ull << end_bit) < nkeys) end_bit++;
+        size_t tb = tmp2;
+        TRYC(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (int)npos, 0, end_bit));
+    }
+    hipLaunchKernelGGL(split_counts, dim3((total + 1 + 255) / 256), dim3(256), 0, 0, d_off2, d_cnt, total, (uint32_t)npos, c->d_koff, c->d_knfwd);
+    TRYC(hipGetLastError());
+    TRYC(hipDeviceSynchronize());
+    c->d_locs = d_vals2;
+    d_vals2 = nullptr;
+    c->nlocs = npos;
+    // over-represented k-mer cut-off (refbase.cpp:362-363) from the per-k-mer totals
+    {
+        std::vector<uint32_t> off((size_t)total + 1);
+        TRYC(hipMemcpy(off.data(), c->d_koff, ((size_t)total + 1) * 4, hipMemcpyDeviceToHost));
+        uint32_t idx = kmer_cutoff_index(total, c->p.max_kmer_ratio);
+        uint32_t mk;
+        if (idx >= total - 1) mk = off[total] - off[total - 1];
+        else {
+            uint32_t mx = 0;
+            for (uint32_t k = 0; k + 1 < total; k++) mx = std::max(mx, off[k + 1] - off[k]);
+            std::vector<uint64_t> hist((size_t)mx + 1, 0);
+            for (uint32_t k = 0; k + 1 < total; k++) hist[off[k + 1] - off[k]]++;
+            uint64_t run = 0;
+            uint32_t v = 0;
+            for (; v <= mx; v++) {
+                run += hist[v];
+                if (run > idx) break;
+            }
+            mk = v;
+        }
+        c->max_kmer_num = mk;
+    }
+    cleanup();
+#undef TRYC
+    c->have_index = true;
+    if (max_kmer_num_out) *max_kmer_num_out = c->max_kmer_num;
+    return BASAL_OK;
+}

@@ -3,4 +3,5 @@
 #include <string>
 namespace basal {
 void set_error(const std::string &s);  // text returned by basal_last_error()
+uint32_t kmer_cutoff_index(uint32_t total_kmers, float ratio);  // refbase.cpp:363, single precision
 }

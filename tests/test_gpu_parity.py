@@ -94,3 +94,33 @@ def test_cli_sam_matches_golden(name, tmp_path):
     assert r.returncode == 0, r.stderr
     got = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+@pytest.mark.parametrize("name", ["ct_n1_dirty", "tx_ag_150", "rep_r1", "v_frac05_I2", "c1_s16"])
+def test_gpu_index_build_matches_cpu_build(name):
+    """basal_core_build_index (counting + stable radix sort on the GPU) == the host build == the oracle."""
+    fa = H.fixture_paths(name)[0]
+    flags = H.MANIFEST[name]["flags"]
+    p = B.Params(H.rule_of(flags), flags)
+    ref = B.Reference(p, fasta_path=fa)
+    ref.build_index(4)
+    off, nfwd, locs, mk = ref.index()
+    core = B.Core(p)
+    mk_gpu = core.upload(ref, build_on_gpu=True)
+    goff, gnfwd, glocs, gmk = core.get_index(len(nfwd))
+    assert mk_gpu == mk == gmk
+    assert np.array_equal(goff, off)
+    assert np.array_equal(gnfwd, nfwd)
+    assert np.array_equal(glocs, locs)
+
+
+def test_cli_with_gpu_index(tmp_path):
+    name = "acgt_g2"
+    fa, fq, _, _ = H.fixture_paths(name)
+    out = tmp_path / "o.sam"
+    env = {k: v for k, v in os.environ.items() if k != "BASAL_CPU_INDEX"}
+    r = subprocess.run([BASAL_BIN, "-a", fq, "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "2", "-o", str(out)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "seed table (GPU)" in r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)
