@@ -82,6 +82,7 @@ SYMBOLS = [
     ("basal_core_get_index", _i, [_vp, _vp, _vp, _vp, _P(_u64), _P(_u32)]),
     ("basal_core_align_batch", _i, [_vp, _vp, _u64, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _P(_u64), _vp]),
     ("basal_core_align_batch_device", _i, [_vp, _vp, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
+    ("basal_core_sync_check", _i, [_vp]),
     ("basal_core_set_timing", _i, [_vp, _i]),
     ("basal_core_last_kernel_ms", C.c_float, [_vp]),
     ("basal_core_launch_info", _i, [_vp, _P(_u32), _P(_u32), _P(_u32)]),

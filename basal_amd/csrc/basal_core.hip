@@ -792,6 +792,7 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
     memcpy(tabs + 1024, p->rev_alphabet_mread, 256);
     HIP_TRY(hipMemcpy(c->d_tables, tabs, sizeof tabs, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&c->d_counter, 32 * sizeof(unsigned int)));
+    HIP_TRY(hipMemset(c->d_counter, 0, 32 * sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&c->d_used, sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -912,6 +913,18 @@ extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_
     return BASAL_OK;
 }
 
+static int report_guard(const unsigned int *guard) {
+    static const char *kind[8] = {"k-mer id", "location-list index", "reference word", "base offset", "seed slot", "stale overlay k-mer",
+                                  "k-mer id of a mode seed (value = pos|seg<<16|chain<<24|mode<<26)", "watchdog (a loop did not terminate, or a partial wave)"};
+    for (int k = 0; k < 8; k++)
+        if (guard[k]) {
+            g_err = std::string("align: internal bounds violation (") + kind[k] + "): " + std::to_string(guard[k]) + " times, first value " +
+                    std::to_string(guard[8 + k]) + " at read " + std::to_string(guard[16 + k]);
+            return BASAL_EDEVICE;
+        }
+    return BASAL_OK;
+}
+
 // max_len: the longest read of the batch, selects the kernel instantiation
 static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale, uint32_t max_len,
                         int stream_mode, void *d_results,
@@ -940,7 +953,7 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     c->nwt = nwt;
     bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
     kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp) : nwt == 8 ? pick_kernel<8>(nr, gp) : pick_kernel<16>(nr, gp);
-    HIP_TRY(hipMemsetAsync(c->d_counter, 0, 32 * sizeof(unsigned int), s));
+    HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
     cx.guard = c->d_counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
     uint32_t grid = c->grid;
@@ -960,7 +973,18 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         fprintf(stderr, "[basal debug] align kernel finished\n");
     }
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, s)); c->timed = true; }
+    c->last_stream = s;
     return BASAL_OK;
+}
+
+extern "C" int basal_core_sync_check(basal_core_t *c) {
+    if (!c) { g_err = "sync_check: null argument"; return BASAL_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned int guard[24];
+    HIP_TRY(hipMemcpyAsync(guard, c->d_counter + 1, sizeof guard, hipMemcpyDeviceToHost, c->last_stream));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, sizeof guard, c->last_stream));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    return report_guard(guard);
 }
 
 extern "C" int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
@@ -1034,14 +1058,10 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     unsigned int guard[24];
     HIP_TRY(hipMemcpyAsync(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(guard, c->d_counter + 1, sizeof guard, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, sizeof guard, s));
     HIP_TRY(hipStreamSynchronize(s));
-    for (int k = 0; k < 8; k++)
-        if (guard[k]) {
-            static const char *kind[8] = {"k-mer id", "location-list index", "reference word", "base offset", "seed slot", "stale overlay k-mer", "k-mer id of a mode seed (value = pos|seg<<16|chain<<24|mode<<26)", "watchdog (a loop did not terminate)"};
-            g_err = std::string("align_batch: internal bounds violation (") + kind[k] + "): " + std::to_string(guard[k]) + " times, first value " +
-                    std::to_string(guard[8 + k]) + " at read " + std::to_string(guard[16 + k]);
-            return BASAL_EDEVICE;
-        }
+    if (int gr = report_guard(guard)) return gr;
+
     if (stream_used) *stream_used = used;
     int ret = BASAL_OK;
     if (stream_mode != BASAL_STREAM_NONE) {

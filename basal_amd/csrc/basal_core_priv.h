@@ -31,7 +31,7 @@ struct basal_core {
     basal_result *d_results = nullptr;
     basal_hit *d_stream = nullptr; size_t cap_stream = 0;
     unsigned long long *d_used = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, timed = false;
 };

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s of the BASAL seed-and-extend hot path on MI355X.
+
+Workload (BASELINE.json config 2): synthetic 100 bp SE reads, -M C:T, -g 0, -S 1, on an
+hg38-sized stand-in genome (tools/synth_gpu.py; hg38 itself is not on the GPU box), reference and
+seed index resident in HBM.  A "step" is ONE call of basal_core_align_batch_device on one batch
+of reads that is already in HBM (descriptors + bases in, 32-byte results out, results stay in HBM).
+Timing: W warm-up steps, then K steps between barrier + synchronize, max over ranks;
+value = reads aligned by all ranks / that time.  N > 1 (torchrun): every rank holds the whole
+reference + index, takes its own reads (weak scaling), and the per-read results are gathered to
+rank 0 with ONE RCCL gather inside the timed region.
+
+Extra objects on the JSON line:
+  roofline      algorithmic bytes (4H+16S+4C+8W+L+16R per read, counters from the CPU
+                oracle on a sample of the same reads) / mean kernel time from HIP events on the launch stream.
+  cpu_baseline  the CPU oracle (C restatement, pthreads) timed on this box's host cores on a bounded sample
+                of the same reads with the same index; the GPU results for that sample are checked against it.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1_000_000, help="reads per step and rank")
+    ap.add_argument("--genome-scale", type=float, default=float(os.environ.get("BASAL_BENCH_SCALE", "1.0")), help="1.0 = hg38-sized (3.09 Gbp)")
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads of the cpu_baseline / parity sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--rule", default="C:T")
+    ap.add_argument("--gap", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import basal_amd as B
+    from basal_amd import core as bc
+    import synth_gpu
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    flags = ["-M", args.rule, "-S", "1"] + (["-g", str(args.gap)] if args.gap else [])
+    params = B.Params(args.rule, flags)
+    L = B.lib()
+
+    # ---- reference + index, staged once -----------------------------------------------------
+    t0 = time.time()
+    G = synth_gpu.make_genome(params, dev, scale=args.genome_scale, seed=1)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    words = [w.cpu().numpy().view(np.uint64) for w in G.words]
+    sizes = np.array(G.sizes, dtype=np.uint32)
+    core = B.Core(params, local)
+    t0 = time.time()
+    bc._check(L.basal_core_set_reference(core.h, words[0].ctypes.data, words[1].ctypes.data, len(words[0]), G.anchors.ctypes.data,
+                                         sizes.ctypes.data, G.rc_offsets.ctypes.data, len(sizes)), "set_reference")
+    mk = C.c_uint32()
+    blocks = np.ascontiguousarray(G.blocks)
+    bc._check(L.basal_core_build_index(core.h, blocks.ctypes.data, len(blocks), C.byref(mk)), "build_index")
+    t_index = time.time() - t0
+    total_bp = int(sizes.sum())
+    log("genome %.3f Gbp in %d contigs generated in %.1f s; reference staged + seed index built on the GPU in %.1f s (cut-off %d)"
+        % (total_bp / 1e9, len(sizes), t_gen, t_index, mk.value))
+
+    # ---- reads resident in HBM -----------------------------------------------------------------
+    n_steps = args.steps + args.warmup
+    n_reads = args.batch * n_steps
+    read_len = 100
+    frm, to = "ACGT".index(args.rule[0].upper()), "ACGT".index(args.rule[2].upper()) if args.rule[2] in "ACGTacgt" else None
+    chunks = []
+    per = 2_000_000
+    for c0 in range(0, n_reads, per):
+        nb = min(per, n_reads - c0)
+        b, _, _, _ = synth_gpu.make_reads(G, nb, dev, read_len=read_len, seed=1000 * (rank + 1) + c0 // per, conv_from=frm,
+                                          conv_to=to if to is not None else frm, p_conv=0.95 if to is not None else 0.0)
+        chunks.append(b)
+    d_bases = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
+    del chunks
+    # read_max_snp_num as FilterReads computes it for this length (product host code)
+    seq = C.create_string_buffer(b"A" * read_len, read_len + 2)
+    qual = C.create_string_buffer(b"I" * read_len, read_len + 2)
+    ms = C.c_uint32()
+    assert L.basal_host_filter_read(C.byref(params.c), seq, qual, C.byref(ms)) == 0
+    descs = np.zeros(n_reads, bc.READ_DTYPE)
+    descs["seq_off"] = np.arange(n_reads, dtype=np.uint64) * read_len
+    descs["index"] = np.arange(n_reads, dtype=np.uint32) + rank * n_reads  # global read numbers (myrand)
+    descs["len"] = read_len
+    descs["max_snp"] = ms.value
+    descs["stale_idx"] = B.STALE_NONE
+    d_reads = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(dev)
+    d_results = torch.zeros(n_reads * 32, dtype=torch.uint8, device=dev)
+    d_used = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    core.set_timing(True)
+
+    def step(i):
+        rc = L.basal_core_align_batch_device(core.h, d_bases.data_ptr(), d_reads.data_ptr() + i * args.batch * 16, args.batch, None, 0,
+                                             B.STREAM_NONE, d_results.data_ptr() + i * args.batch * 32, None, 0, d_used.data_ptr(), None,
+                                             read_len, stream)
+        bc._check(rc, "align_batch_device")
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    kernel_ms = []
+    gathered = [torch.empty_like(d_results[args.warmup * args.batch * 32:]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        step(i)
+        kernel_ms.append(core.kernel_ms())  # waits for this step's stop event (HIP events on the launch stream)
+    bc._check(L.basal_core_sync_check(core.h), "align kernels")
+    if world > 1:  # the one collective of the path: per-read results to the rank that writes SAM
+        dist.gather(d_results[args.warmup * args.batch * 32:], gathered, dst=0)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    reads_timed = args.batch * args.steps * world
+
+    res = np.frombuffer(d_results.cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE)
+    timed = res[args.warmup * args.batch:]
+    aligned = int((timed["best_level"] != 0xFF).sum())
+    unique = int(((timed["best_level"] != 0xFF) & (timed["n_hit"].astype(np.uint32) + timed["n_chit"] == 1)).sum())
+    blocks_, threads_, lds_ = core.launch_info()
+
+    out = {
+        "metric": "Mreads/s aligned (100 bp SE, -M C:T, hg38) at 1/2/4/8 GPUs; SAM bit-identical",
+        "value": reads_timed / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": "config 2: %d M synthetic 100 bp SE reads per GPU (%d per step), -M %s -g %d -S 1, hg38-sized synthetic genome "
+                               "(%.2f Gbp, %d contigs, N gaps, planted repeats), reference + seed index resident in HBM, reads resident in HBM"
+                               % (args.batch * args.steps // 1_000_000, args.batch, args.rule, args.gap, total_bp / 1e9, len(sizes)),
+                   "reads_per_step_per_gpu": args.batch, "genome_bp": total_bp, "index_entries": None, "aligned_frac": aligned / max(1, len(timed)),
+                   "unique_frac": unique / max(1, len(timed)), "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
+                   "index_build_s": round(t_index, 2)},
+    }
+
+    # ---- cpu_baseline + parity on a bounded sample (rank 0, N=1 only) + roofline ------------------
+    cpu = None
+    roof = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import oracle as orc
+        ns = min(args.cpu_sample, args.batch * args.steps)
+        OL = orc.lib()
+        tk = 3 ** params.c.seed_size
+        off, nfwd, locs, mk2 = core.get_index(tk)
+        out["config"]["index_entries"] = int(len(locs))
+        n_tot = np.diff(off.astype(np.uint64)).astype(np.uint32)
+        off64 = off.astype(np.uint64)
+        op = orc.make_param(flags)
+        op.max_kmer_num = mk2
+        names = (C.c_char_p * len(sizes))(*[n.encode() for n in G.names])
+        oref = OL.orc_ref_from_arrays(len(sizes), names, sizes.ctypes.data, words[0].ctypes.data, words[1].ctypes.data, len(words[0]), tk,
+                                      n_tot.ctypes.data, nfwd.ctypes.data, off64.ctypes.data, locs.ctypes.data, len(locs))
+        first = args.warmup * args.batch
+        sb = d_bases[first * read_len:(first + ns) * read_len].cpu().numpy()
+        sd = descs[first:first + ns]
+        seq_off = (sd["seq_off"] - first * read_len).astype(np.uint32)
+        lens = sd["len"].astype(np.uint16)
+        idx = sd["index"].astype(np.uint32)
+        msn = sd["max_snp"].astype(np.uint8)
+
+        class orc_best(C.Structure):
+            _fields_ = [(n, C.c_uint32) for n in ("best_level", "n_hit", "n_chit", "chr", "loc")] + [("gap_size", C.c_int32), ("gap_pos", C.c_uint32), ("chain", C.c_uint32)]
+        best = np.zeros(ns, dtype=np.dtype([("best_level", "<u4"), ("n_hit", "<u4"), ("n_chit", "<u4"), ("chr", "<u4"), ("loc", "<u4"),
+                                            ("gap_size", "<i4"), ("gap_pos", "<u4"), ("chain", "<u4")]))
+        cnt = orc.orc_counters()
+        secs = C.c_double()
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        OL.orc_align_batch_mt.argtypes = [C.POINTER(orc.orc_param), C.POINTER(orc.orc_ref), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_uint32, C.c_int, C.c_void_p, C.POINTER(orc.orc_counters), C.POINTER(C.c_double)]
+        OL.orc_align_batch_mt(C.byref(op), oref, sb.ctypes.data, seq_off.ctypes.data, lens.ctypes.data, idx.ctypes.data, msn.ctypes.data, ns, threads,
+                              best.ctypes.data, C.byref(cnt), C.byref(secs))
+        gpu = timed[:ns]
+        same = ((gpu["best_level"].astype(np.uint32) == (best["best_level"] & 0xFF)) & (gpu["n_hit"] == best["n_hit"]) & (gpu["n_chit"] == best["n_chit"]))
+        hit = best["best_level"] != 0xFF
+        same &= ~hit | ((gpu["best"]["loc"] == best["loc"]) & (gpu["best"]["chr"] == best["chr"]) & (gpu["best"]["chain"] == best["chain"]))
+        nbad = int((~same).sum())
+        if nbad:
+            raise SystemExit("bench: %d of %d sampled reads differ between the GPU path and the CPU oracle -- number withheld" % (nbad, ns))
+        Bread = (4 * cnt.hdr_lookups + 16 * cnt.seed_lookups + 4 * cnt.candidates + 8 * cnt.ref_words + cnt.read_bytes + 16 * cnt.hit_records) / ns
+        cpu = {"value": ns / secs.value / 1e6, "unit": "Mreads/s", "cores": threads, "kind": "port",
+               "sample": "%d reads of the timed workload, same index; GPU results identical to the oracle on all of them" % ns}
+        out["config"]["algorithmic_bytes_per_read"] = round(Bread, 1)
+        out["config"]["counters_per_read"] = {"H": cnt.hdr_lookups / ns, "S": cnt.seed_lookups / ns, "C": cnt.candidates / ns, "W": cnt.ref_words / ns,
+                                              "L": cnt.read_bytes / ns, "R": cnt.hit_records / ns}
+        mean_ms = float(np.mean(kernel_ms))
+        ach = Bread * args.batch / (mean_ms * 1e-3) / 1e9
+        roof.update({"achieved": ach, "frac": ach / 8000.0, "kernel": "align_kernel<4,false,false>", "kernel_ms": mean_ms,
+                     "bytes_per_launch": Bread * args.batch})
+    else:
+        roof["kernel_ms"] = float(np.mean(kernel_ms)) if kernel_ms else None
+    out["roofline"] = roof
+    out["cpu_baseline"] = cpu
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -170,6 +170,11 @@ int basal_core_align_batch_device(basal_core_t *c, const void *d_bases, const vo
                                   void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2],
                                   uint32_t max_len, void *hip_stream);
 
+/* Wait for the work queued by the last align_batch_device call and report what the kernel's bounds
+ * ledger recorded: BASAL_OK, or BASAL_EDEVICE with the kind of violation in basal_last_error()
+ * (an index outside its array is never dereferenced on the device; it is counted instead). */
+int basal_core_sync_check(basal_core_t *c);
+
 /* Kernel-time instrumentation: milliseconds of the last align_batch* kernel measured with HIP
  * events on the stream it ran on (0 if timing is off). */
 int basal_core_set_timing(basal_core_t *c, int on);

@@ -1299,3 +1299,92 @@ void orc_sam_header(const orc_ref *r, const char *cmdline, orc_str *os) {
 }
 
 #include "basal_oracle_pe.inc"
+
+/* ------------------------------------------------------------------ in-memory batch driver (bench/spot checks) */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct mt_job {
+    const orc_param *p;
+    const orc_ref *r;
+    const uint8_t *bases;
+    const uint32_t *seq_off, *index;
+    const uint16_t *len;
+    const uint8_t *max_snp;
+    uint32_t begin, end;
+    orc_best *out;
+    orc_counters c;
+} mt_job;
+
+static void *mt_worker(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    orc_aligner *a = orc_aligner_new(j->p, j->r);
+    char seq[ORC_FIXSIZE + 8], qual[ORC_FIXSIZE + 8], name[4] = "r";
+    for (uint32_t i = j->begin; i < j->end; i++) {
+        uint32_t L = j->len[i];
+        orc_best *o = &j->out[i];
+        memset(o, 0, sizeof *o);
+        o->best_level = 0xFF;
+        if (L == 0 || L > ORC_FIXSIZE) continue;
+        memcpy(seq, j->bases + j->seq_off[i], L);
+        seq[L] = 0;
+        memset(qual, 'I', L);
+        qual[L] = 0;
+        orc_read rd = {j->index[i], 0, name, seq, qual};
+        /* the reads are post-FilterReads: take read_max_snp_num as given */
+        a->read_max_snp_num = j->max_snp[i];
+        a->raw_readlen = L;
+        orc_run_align(a, &rd);
+        uint32_t ii, sum = 0;
+        for (ii = 0; ii <= a->read_max_snp_num; ii++)
+            if ((sum = a->x_cur_n_hit[0][ii] + a->x_cur_n_hit[1][ii]) > 0) break;
+        if (!sum) continue;
+        uint32_t nh = a->x_cur_n_hit[0][ii], jj = sum == 1 ? 0 : orc_myrand((int)rd.index, j->p->randseed) % sum;
+        const orc_hit *h = jj < nh ? &a->xhits[0][ii][jj] : &a->xhits[1][ii][jj - nh];
+        o->best_level = ii;
+        o->n_hit = nh;
+        o->n_chit = a->x_cur_n_hit[1][ii];
+        o->chr = h->chr;
+        o->loc = h->loc;
+        o->gap_size = h->gap_size;
+        o->gap_pos = h->gap_pos;
+        o->chain = jj < nh ? 0 : 1;
+        a->c.hit_records++;
+    }
+    j->c = a->c;
+    orc_aligner_free(a);
+    return NULL;
+}
+
+int orc_align_batch_mt(const orc_param *p, const orc_ref *r, const uint8_t *bases, const uint32_t *seq_off, const uint16_t *len,
+                       const uint32_t *index, const uint8_t *max_snp, uint32_t n, int threads, orc_best *out, orc_counters *counters,
+                       double *seconds) {
+    if (threads < 1) threads = 1;
+    if ((uint32_t)threads > n && n) threads = (int)n;
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    mt_job *jobs = (mt_job *)calloc((size_t)threads, sizeof(mt_job));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        mt_job *j = &jobs[t];
+        j->p = p; j->r = r; j->bases = bases; j->seq_off = seq_off; j->len = len; j->index = index; j->max_snp = max_snp; j->out = out;
+        j->begin = (uint32_t)((uint64_t)n * t / threads);
+        j->end = (uint32_t)((uint64_t)n * (t + 1) / threads);
+        pthread_create(&th[t], NULL, mt_worker, j);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds) *seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    if (counters) {
+        memset(counters, 0, sizeof *counters);
+        for (int t = 0; t < threads; t++) {
+            const orc_counters *c = &jobs[t].c;
+            counters->reads += c->reads; counters->hdr_lookups += c->hdr_lookups; counters->seed_lookups += c->seed_lookups;
+            counters->candidates += c->candidates; counters->ref_words += c->ref_words; counters->read_bytes += c->read_bytes;
+            counters->hit_records += c->hit_records; counters->snp_calls += c->snp_calls; counters->gap_calls += c->gap_calls;
+        }
+    }
+    free(th);
+    free(jobs);
+    return 0;
+}

@@ -175,6 +175,18 @@ void orc_do_pair(orc_pair_aligner *pa, orc_read *ra, orc_read *rb, orc_str *os);
 void orc_pair_stats(const orc_pair_aligner *pa, uint32_t out[9]);
 const orc_counters *orc_pair_counters(orc_pair_aligner *pa, int mate);
 
+/* Batch driver used by bench.py's cpu_baseline leg and by at-scale spot checks: aligns n SE reads
+ * that are already in memory with `threads` pthreads (one orc_aligner each, contiguous slices) and
+ * returns, per read, what StringAlign would pick.  out[i] = {best_level (0xFF none), n_hit, n_chit,
+ * chr, loc, gap_size, gap_pos, chain}.  Fills *seconds (wall, monotonic) and sums the counters. */
+typedef struct orc_best {
+    uint32_t best_level, n_hit, n_chit, chr, loc;
+    int32_t gap_size;
+    uint32_t gap_pos, chain;
+} orc_best;
+int orc_align_batch_mt(const orc_param *p, const orc_ref *r, const uint8_t *bases, const uint32_t *seq_off, const uint16_t *len,
+                       const uint32_t *index, const uint8_t *max_snp, uint32_t n, int threads, orc_best *out, orc_counters *counters,
+                       double *seconds);
 #ifdef __cplusplus
 }
 #endif

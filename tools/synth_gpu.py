@@ -1,0 +1,146 @@
+"""Synthetic genome-scale workload generated ON the GPU with torch (bench / at-scale test tooling).
+
+hg38 is not on the GPU box, so BASELINE.json's config 2 ("10 M x 100 bp SE, -M C:T, hg38") runs on
+a stand-in: 24 contigs with hg38's chromosome sizes (3.09 Gbp), uniform ACGT, N gaps
+(one "centromere" per contig plus short gaps) and a planted diverged repeat family.  Because the
+seed index hashes 3-letter-reduced 16-mers every 4th base of both strands, a uniform 3.1 Gbp
+genome already gives hg38's mean index density (~36 locations per seed).
+Reads: uniform start in non-N sequence, 50 % reverse strand, revcomp THEN convert (directional
+protocol), per-base substitution rate.  Everything is seeded; torch only provides device memory
+and elementwise ops -- none of this is part of the product path.
+"""
+import numpy as np
+import torch
+
+HG38_SIZES = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+              138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+              83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+MARGIN = 400
+
+
+def _codes(params):
+    """base id (A,C,G,T = 0..3) -> 2-bit code, forward and for the complement."""
+    al = [params.c.alphabet[ord(b)] for b in "ACGT"]
+    rv = [params.c.rev_alphabet[ord(b)] for b in "ACGT"]
+    return al, rv
+
+
+def _pack(codes_u8):
+    """uint8 codes, length multiple of 32 -> int64 words, base 0 in the top two bits."""
+    sh = torch.arange(31, -1, -1, device=codes_u8.device, dtype=torch.int64) * 2
+    return (codes_u8.view(-1, 32).to(torch.int64) << sh).sum(dim=1)
+
+
+class Genome:
+    pass
+
+
+def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=40000, repeat_len=300, repeat_div=0.12):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    sizes = [max(20000, int(s * scale)) for s in HG38_SIZES[:n_contigs]]
+    al, rv = _codes(params)
+    al_t = torch.tensor(al, dtype=torch.uint8, device=device)
+    rv_t = torch.tensor(rv, dtype=torch.uint8, device=device)
+    family = torch.randint(0, 4, (repeat_len,), generator=g, device=device, dtype=torch.uint8)
+    G = Genome()
+    G.names, G.sizes, G.ids, G.nmask_runs = NAMES[:n_contigs], sizes, [], []
+    fw_words, rc_words, blocks = [], [], []
+    anchors = [MARGIN * 32]
+    s_words = 0
+    per_contig_rep = max(1, int(repeat_copies * scale) // n_contigs)
+    for ci, L in enumerate(sizes):
+        ids = torch.randint(0, 4, (L,), generator=g, device=device, dtype=torch.uint8)
+        # planted repeat family, diverged copies
+        if per_contig_rep and L > 4 * repeat_len:
+            starts = torch.from_numpy(rng.integers(0, L - repeat_len, size=per_contig_rep)).to(device)
+            idx = (starts[:, None] + torch.arange(repeat_len, device=device)[None, :]).reshape(-1)
+            unit = family.repeat(per_contig_rep)
+            mut = torch.rand(unit.shape, generator=g, device=device) < repeat_div
+            unit = torch.where(mut, torch.randint(0, 4, unit.shape, generator=g, device=device, dtype=torch.uint8), unit)
+            ids[idx] = unit
+        # N runs: one large block in the middle, a few short gaps
+        runs = []
+        if L > 2_000_000:
+            c0 = L // 2 - L // 100
+            runs.append((c0, c0 + L // 50))
+            for k in range(4):
+                p = int(rng.integers(L // 10, L - L // 10))
+                runs.append((p, p + 50_000))
+        elif L > 100_000:
+            runs.append((L // 2, L // 2 + 1000))
+        runs = sorted(runs)
+        merged = []
+        for a, b in runs:
+            if merged and a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        isn = torch.zeros(L, dtype=torch.bool, device=device)
+        for a, b in merged:
+            isn[a:b] = True
+        n = (L + 31) // 32 + 2
+        tot = n * 32
+        code_f = torch.zeros(tot, dtype=torch.uint8, device=device)
+        code_f[:L] = torch.where(isn, torch.zeros_like(ids), al_t[ids.long()])
+        code_r = torch.zeros(tot, dtype=torch.uint8, device=device)
+        code_r[tot - L:] = torch.where(isn, torch.zeros_like(ids), rv_t[ids.long()]).flip(0)
+        fw_words.append(_pack(code_f))
+        rc_words.append(_pack(code_r))
+        # unmasked blocks (refbase.cpp:103-128) and their reverse-strand twins
+        prev = 0
+        for a, b in merged + [(L, L)]:
+            if a - prev >= 16:
+                blocks.append((2 * ci, prev, a))
+                blocks.append((2 * ci + 1, tot - a, tot - prev))
+            prev = b
+        G.ids.append(ids)
+        G.nmask_runs.append(merged)
+        s_words += n
+        anchors.append((s_words + MARGIN) * 32)
+        del code_f, code_r, isn
+    pad = torch.zeros(MARGIN, dtype=torch.int64, device=device)
+    G.words = [torch.cat([pad] + fw_words + [pad]), torch.cat([pad] + rc_words + [pad])]
+    G.anchors = np.array(anchors, dtype=np.uint32)
+    G.rc_offsets = np.array([((L + 31) // 32 + 2) * 32 for L in sizes], dtype=np.uint32)
+    blocks.sort(key=lambda t: (t[0], t[1]))
+    G.blocks = np.array(blocks, dtype=np.uint32).reshape(-1, 3)
+    return G
+
+
+def make_reads(G, n, device, read_len=100, seed=2, p_conv=0.95, sub_rate=0.01, rev_frac=0.5, conv_from=1, conv_to=3):
+    """n reads as ASCII bytes (n*read_len uint8 tensor) plus the truth (contig, 0-based start, strand)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    # sample (contig, start) uniformly over non-N stretches long enough for a read
+    segs = []
+    for ci, runs in enumerate(G.nmask_runs):
+        prev = 0
+        for a, b in runs + [(G.sizes[ci], G.sizes[ci])]:
+            if a - prev > read_len + 1:
+                segs.append((ci, prev, a - read_len))
+            prev = b
+    seg_len = torch.tensor([e - s for _, s, e in segs], dtype=torch.float64)
+    pick = torch.multinomial(seg_len / seg_len.sum(), n, replacement=True, generator=torch.Generator().manual_seed(seed)).to(device)
+    seg_ci = torch.tensor([c for c, _, _ in segs], device=device)[pick]
+    seg_s = torch.tensor([s for _, s, _ in segs], device=device, dtype=torch.int64)[pick]
+    seg_e = torch.tensor([e for _, _, e in segs], device=device, dtype=torch.int64)[pick]
+    start = seg_s + (torch.rand(n, generator=g, device=device, dtype=torch.float64) * (seg_e - seg_s).double()).long()
+    out = torch.empty((n, read_len), dtype=torch.uint8, device=device)
+    ar = torch.arange(read_len, device=device)
+    for ci in range(len(G.sizes)):
+        m = (seg_ci == ci).nonzero(as_tuple=True)[0]
+        if m.numel() == 0:
+            continue
+        out[m] = G.ids[ci][(start[m][:, None] + ar[None, :])]
+    rev = torch.rand(n, generator=g, device=device) < rev_frac
+    out = torch.where(rev[:, None], (3 - out).flip(1), out)
+    conv = (out == conv_from) & (torch.rand(out.shape, generator=g, device=device) < p_conv)
+    out = torch.where(conv, torch.full_like(out, conv_to), out)
+    sub = torch.rand(out.shape, generator=g, device=device) < sub_rate
+    out = torch.where(sub, (out + torch.randint(1, 4, out.shape, generator=g, device=device, dtype=torch.uint8)) % 4, out)
+    ascii_t = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    bases = ascii_t[out.long()].reshape(-1).contiguous()
+    return bases, seg_ci, start, rev
