@@ -909,7 +909,14 @@ extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_
     if (rc) return rc;
     if (blocks) *blocks = c->grid;
     if (threads) *threads = 256;
-    if (lds_bytes) *lds_bytes = c->nwt == 16 ? (uint32_t)(4 * sizeof(WaveLds<16>) + 1280) : c->nwt == 8 ? (uint32_t)(4 * sizeof(WaveLds<8>) + 1280) : (uint32_t)(4 * sizeof(WaveLds<4>) + 1280);
+    if (lds_bytes) {
+        int nwt = c->nwt ? c->nwt : 4;
+        bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
+        kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp) : nwt == 8 ? pick_kernel<8>(nr, gp) : pick_kernel<16>(nr, gp);
+        hipFuncAttributes at;
+        HIP_TRY(hipFuncGetAttributes(&at, (const void *)k));
+        *lds_bytes = (uint32_t)at.sharedSizeBytes;
+    }
     return BASAL_OK;
 }
 

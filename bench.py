@@ -228,6 +228,21 @@ def main():
                      "bytes_per_launch": Bread * args.batch})
     else:
         roof["kernel_ms"] = float(np.mean(kernel_ms)) if kernel_ms else None
+    # HBM traffic per read from the PMC passes of this same command (profiles/traffic.json, if committed)
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj) and world == 1:
+        t = json.load(open(tj))
+        roof["traffic"] = t["hbm_bytes_per_read"] * args.batch
+        roof["traffic_source"] = t["source"]
+    # PCIe-inclusive rate (host buffers in, host buffers out) -- reported next to value, never as value
+    if rank == 0 and world == 1:
+        hb = d_bases[: args.batch * read_len].cpu().numpy()
+        hd = descs[: args.batch].copy()
+        core.align_batch(hb, hd)  # warm the staging buffers
+        t1 = time.perf_counter()
+        for _ in range(2):
+            core.align_batch(hb, hd)
+        out["config"]["pcie_inclusive_mreads_per_s"] = round(2 * args.batch / (time.perf_counter() - t1) / 1e6, 2)
     out["roofline"] = roof
     out["cpu_baseline"] = cpu
     if rank == 0:
