@@ -6,6 +6,6 @@ that ABI for tests and bench.py; it contains no alignment logic and no CPU fallb
 """
 from .core import (  # noqa: F401
     BasalError, Core, Params, Reference, lib, lib_path, build,
-    basal_hit, basal_read, basal_result, basal_params, basal_stale,
+    basal_hit, basal_read, basal_result, basal_params, basal_stale, basal_mate, READ_ALLMODES,
     STREAM_NONE, STREAM_BEST, STREAM_ALL, STALE_NONE, STALE_CARRY,
 )

@@ -57,6 +57,12 @@ class basal_stale(C.Structure):
     _fields_ = [("src", C.c_uint32), ("overlay", (C.c_uint32 * 15) * 2)]
 
 
+class basal_mate(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("seq", C.c_char_p), ("qual", C.c_char_p), ("readset", C.c_uint32), ("index", C.c_uint32),
+                ("max_snp", C.c_uint32), ("qc_failed", C.c_int), ("res", C.POINTER(basal_result))]
+
+
+READ_ALLMODES = 0x80
 HIT_DTYPE = np.dtype([("loc", "<u4"), ("chr", "<u4"), ("gap_size", "i1"), ("strand", "u1"), ("gap_pos", "<u2"),
                       ("level", "u1"), ("chain", "u1"), ("mode", "u1"), ("pad", "u1")])
 RESULT_DTYPE = np.dtype([("best", HIT_DTYPE), ("n_hit", "<u2"), ("n_chit", "<u2"), ("best_level", "u1"),
@@ -118,6 +124,8 @@ SYMBOLS = [
     ("basal_host_filter_read", _i, [_P(basal_params), C.c_char_p, C.c_char_p, _P(_u32)]),
     ("basal_host_format_se", C.c_int64, [_P(basal_params), _vp, C.c_char_p, C.c_char_p, C.c_char_p, _u32, _i,
                                          _P(basal_result), _vp, C.c_char_p, C.c_size_t]),
+    ("basal_host_format_pe", C.c_int64, [_P(basal_params), _vp, _P(basal_mate), _P(basal_mate), _vp, C.c_char_p, C.c_size_t, _P(_u32)]),
+    ("basal_host_fix_pair_names", _i, [C.c_char_p, C.c_char_p]),
     ("basal_host_sam_header", C.c_int64, [_vp, C.c_char_p, C.c_char_p, C.c_size_t]),
 ]
 

@@ -171,12 +171,12 @@ template <int NWT>
 __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane) {
     rc.len = rd.len;
     rc.index = rd.index;
-    rc.readset = rd.readset;
+    const uint32_t rs = rd.readset & 0x7fu;
+    rc.readset = rs;
     rc.max_snp = rd.max_snp;
     rc.seq_off = rd.seq_off;
     // xflag_chain (align.cpp:83-84)
-    rc.flags = (((cx.chains == 1) || ((cx.chains <= 1) == (rd.readset < 2))) ? 1u : 0u) |
-               (((cx.chains == 1) || ((cx.chains <= 1) == (rd.readset == 2))) ? 2u : 0u);
+    rc.flags = (((cx.chains == 1) || ((cx.chains <= 1) == (rs < 2))) ? 1u : 0u) | (((cx.chains == 1) || ((cx.chains <= 1) == (rs == 2))) ? 2u : 0u);
     {  // seedseg_num (align.cpp:450)
         int x = (int)((rc.len - cx.I + 1) / cx.K), y = (int)(rc.max_snp + 1);
         rc.nseg = (uint32_t)(x < y ? x : y);
@@ -515,6 +515,8 @@ __device__ uint32_t find_kth(const basal_hit *log, uint32_t nlog, uint32_t level
 template <int NWT, bool NEWRULE, bool GAP>
 __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab, basal_hit *log, uint32_t r, int lane) {
     basal_read rd = cx.reads[r];
+    const bool allmodes = (rd.readset & BASAL_READ_ALLMODES) != 0;  // a PE mate: PairAlign::RunAlign drives the modes
+    rd.readset &= 0x7f;
     basal_result res;
     memset(&res, 0, sizeof(res));
     res.best_level = 0xFF;
@@ -666,10 +668,14 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                 if (!recompute || done) break;
             }
         }
-        // RunAlign: stop once any level <= mode holds a hit (align.cpp:462); `done` = AddHit said stop
-        uint32_t any = 0;
-        if ((uint32_t)lane <= mode && lane < 16) any = L.nhit[0][lane] | L.nhit[1][lane];
-        if (__ballot(any != 0)) done = true;
+        // RunAlign: stop once any level <= mode holds a hit (align.cpp:462); `done` = AddHit said stop.
+        // For a PE mate the stop only ends this SnpAlign call; the next mode still runs (pairs.cpp:164-174).
+        if (allmodes) done = false;
+        else {
+            uint32_t any = 0;
+            if ((uint32_t)lane <= mode && lane < 16) any = L.nhit[0][lane] | L.nhit[1][lane];
+            if (__ballot(any != 0)) done = true;
+        }
     }
 
     // ---- StringAlign's choice (align.cpp:583-612) ----
@@ -1081,11 +1087,12 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
         for (int slot = 0; slot < 2; slot++) {
             for (uint32_t i = n; i-- > 0;) {
                 const basal_read &r = reads[i];
-                if (r.len == 0 || (r.readset == 2 ? 1 : 0) != slot) continue;
+                const uint32_t rs = r.readset & 0x7fu;
+                if (r.len == 0 || (rs == 2 ? 1 : 0) != slot) continue;
                 if (results[i].status == BASAL_READ_SKIPPED) continue;
                 // any aligned read leaves a defined value behind (own or inherited)
-                bool f0 = (c->p.chains == 1) || ((c->p.chains <= 1) == (r.readset < 2));
-                bool f1 = (c->p.chains == 1) || ((c->p.chains <= 1) == (r.readset == 2));
+                bool f0 = (c->p.chains == 1) || ((c->p.chains <= 1) == (rs < 2));
+                bool f1 = (c->p.chains == 1) || ((c->p.chains <= 1) == (rs == 2));
                 if (f0) carry[slot][0] = results[i].start_off[0];
                 if (f1) carry[slot][1] = results[i].start_off[1];
                 break;

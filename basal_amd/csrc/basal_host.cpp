@@ -583,6 +583,16 @@ void put_record(Out &o, const basal_params *p, const basal_ref *r, const char *n
 }
 }  // namespace
 
+namespace basal {
+void put_xr_field(char *out, size_t cap, size_t *n, bool *ok, const basal_params *p, const basal_ref_t *r, uint32_t contig, uint32_t loc, uint32_t len) {
+    Out o{out, cap, *n, *ok};
+    put_xr(o, p, r, contig, loc, len);
+    *n = o.n;
+    *ok = o.ok;
+}
+const char *ref_contig_name(const basal_ref_t *r, uint32_t contig) { return contig < r->name.size() ? r->name[contig].c_str() : "*"; }
+}  // namespace basal
+
 extern "C" int64_t basal_host_format_se(const basal_params *p, const basal_ref_t *r, const char *name, const char *seq, const char *qual,
                                         uint32_t readset, int qc_failed, const basal_result *res, const basal_hit *stream, char *out, size_t cap) {
     Out o{out, cap, 0, true};

@@ -215,7 +215,95 @@ int main(int argc, char **argv) {
     double t_gpu = 0, t_host = 0, t3 = now();
     uint8_t carry[2][2] = {{0, 0}, {0, 0}};
     if (P.pairend) {
-        die("pair-end alignment (-b) is not available in this build yet");
+        // PairAlign::Do_Batch (pairs.cpp:179-202): both mates in one GPU batch (a0,b0,a1,b1,...), pairing on the host
+        std::vector<Rec> ra_, rb_;
+        std::vector<uint8_t> bases;
+        std::vector<basal_read> descs;
+        std::vector<basal_result> results;
+        std::vector<basal_hit> stream;
+        std::vector<basal_stale> stales;
+        basal_stale_tracker_t *tracker = basal_host_stale_new(&P);
+        uint32_t pst[9] = {0};
+        for (;;) {
+            int n1 = load_batch(ra, P, read_end, batch / 2 + 1, 1, ra_);
+            int n2 = load_batch(rb, P, read_end, batch / 2 + 1, 2, rb_);
+            if (!n1 || n1 != n2) break;
+            const size_t np = (size_t)n1;
+            parallel_for(np, threads, [&](size_t b, size_t e, int) {
+                for (size_t i = b; i < e; i++) {
+                    ra_[i].qc_failed = basal_host_filter_read(&P, ra_[i].seq.data(), ra_[i].qual.data(), &ra_[i].max_snp);
+                    rb_[i].qc_failed = basal_host_filter_read(&P, rb_[i].seq.data(), rb_[i].qual.data(), &rb_[i].max_snp);
+                }
+            });
+            descs.assign(2 * np, basal_read{});
+            bases.clear();
+            stales.clear();
+            basal_host_stale_begin_batch(tracker);
+            for (size_t i = 0; i < np; i++) {
+                std::vector<char> na(ra_[i].name.begin(), ra_[i].name.end()), nb(rb_[i].name.begin(), rb_[i].name.end());
+                na.push_back(0); nb.push_back(0);
+                if (basal_host_fix_pair_names(na.data(), nb.data())) die(basal_last_error());
+                ra_[i].name = na.data(); rb_[i].name = nb.data();
+                const bool both = !ra_[i].qc_failed && !rb_[i].qc_failed;
+                for (int m = 0; m < 2; m++) {
+                    Rec &rc_ = m ? rb_[i] : ra_[i];
+                    basal_read &d = descs[2 * i + m];
+                    d.index = rc_.index;
+                    d.readset = (uint8_t)((m ? 2 : 1) | (both ? BASAL_READ_ALLMODES : 0));
+                    d.stale_idx = BASAL_STALE_NONE;
+                    if (rc_.qc_failed) { d.len = 0; continue; }
+                    uint32_t len = (uint32_t)strlen(rc_.seq.data());
+                    d.len = (uint16_t)len;
+                    d.max_snp = (uint8_t)rc_.max_snp;
+                    d.seq_off = (uint32_t)bases.size();
+                    bases.insert(bases.end(), rc_.seq.begin(), rc_.seq.begin() + len);
+                    basal_stale se;
+                    if (basal_host_stale_visit(tracker, rc_.seq.data(), len, m ? 2 : 1, 0, (uint32_t)(2 * i + m), &se)) {
+                        d.stale_idx = (uint32_t)stales.size();
+                        stales.push_back(se);
+                    }
+                }
+            }
+            results.assign(2 * np, basal_result{});
+            uint64_t cap = 16 * np + 4096, used = 0;
+            double g0 = now();
+            for (;;) {
+                stream.resize(cap);
+                uint8_t cy[2][2];
+                memcpy(cy, carry, 4);
+                int rc = basal_core_align_batch(core, bases.data(), bases.size(), descs.data(), (uint32_t)(2 * np), stales.data(), (uint32_t)stales.size(),
+                                                BASAL_STREAM_ALL, results.data(), stream.data(), cap, &used, cy);
+                if (rc == BASAL_EOVERFLOW) { cap = used + 4096; continue; }
+                if (rc) die(std::string("align_batch: ") + basal_last_error());
+                memcpy(carry, cy, 4);
+                break;
+            }
+            t_gpu += now() - g0;
+            std::vector<std::string> chunks((size_t)std::max(threads, 1));
+            std::vector<uint32_t> st((size_t)std::max(threads, 1) * 9, 0);
+            parallel_for(np, threads, [&](size_t b, size_t e, int tid) {
+                std::vector<char> line(1 << 16);
+                for (size_t i = b; i < e; i++) {
+                    basal_mate ma{ra_[i].name.c_str(), ra_[i].seq.data(), ra_[i].qual.data(), 1, ra_[i].index, ra_[i].max_snp, ra_[i].qc_failed, &results[2 * i]};
+                    basal_mate mb{rb_[i].name.c_str(), rb_[i].seq.data(), rb_[i].qual.data(), 2, rb_[i].index, rb_[i].max_snp, rb_[i].qc_failed, &results[2 * i + 1]};
+                    size_t need = 8192 + (size_t)(results[2 * i].stream_n + results[2 * i + 1].stream_n + 2 + P.max_num_hits * 2) * (1024 + 2 * (ra_[i].seq.size() + rb_[i].seq.size()));
+                    if (line.size() < need) line.resize(need);
+                    int64_t w = basal_host_format_pe(&P, R, &ma, &mb, stream.data(), line.data(), line.size(), &st[9 * (size_t)tid]);
+                    if (w < 0) die(std::string("format_pe: ") + basal_last_error());
+                    chunks[(size_t)tid].append(line.data(), (size_t)w);
+                }
+            });
+            for (auto &c : chunks) fwrite(c.data(), 1, c.size(), fo);
+            for (size_t t = 0; t < chunks.size(); t++) for (int k = 0; k < 9; k++) pst[k] += st[9 * t + k];
+            n_total += np;
+        }
+        if (verbose >= 1) {
+            uint32_t tot = ra.index - read_start + 1;
+            fprintf(stderr, "[BASAL-MI355X] total read pairs: %u \ttotal time:  %.2f secs (GPU batches %.3f s)\n", tot, now() - t0, t_gpu);
+            fprintf(stderr, "\taligned pairs: %u, unique pairs: %u, non-unique pairs: %u\n\tunpaired read #1: %u, unique: %u, non-unique: %u\n\tunpaired read #2: %u, unique: %u, non-unique: %u\n",
+                    pst[0], pst[1], pst[2], pst[3], pst[4], pst[5], pst[6], pst[7], pst[8]);
+        }
+        basal_host_stale_free(tracker);
     } else {
         std::vector<Rec> recs;
         std::vector<uint8_t> bases;

@@ -106,10 +106,12 @@ typedef struct basal_read {
     uint32_t seq_off;   /* offset of the first base in the batch's base buffer */
     uint32_t index;     /* ReadInf.index: global read number, feeds myrand */
     uint16_t len;       /* 0: skip */
-    uint8_t readset;    /* 0 SE, 1 mate 1, 2 mate 2 */
+    uint8_t readset;    /* 0 SE, 1 mate 1, 2 mate 2; | BASAL_READ_ALLMODES for a mate aligned by PairAlign::RunAlign */
     uint8_t max_snp;    /* read_max_snp_num */
     uint32_t stale_idx; /* BASAL_STALE_NONE, or this read's entry in the batch's basal_stale table */
 } basal_read;
+#define BASAL_READ_ALLMODES 0x80 /* PE (pairs.cpp:164-174): run every SnpAlign mode, no per-read early stop; the host
+                                    replays GetPairs mode by mode over the mode-tagged hit log (BASAL_STREAM_ALL) */
 #define BASAL_STALE_NONE 0xFFFFFFFFu
 #define BASAL_STALE_CARRY 0xFFFFFFFEu
 
@@ -238,6 +240,23 @@ int basal_host_filter_read(const basal_params *p, char *seq, char *qual, uint32_
 int64_t basal_host_format_se(const basal_params *p, const basal_ref_t *r, const char *name, const char *seq,
                              const char *qual, uint32_t readset, int qc_failed, const basal_result *res,
                              const basal_hit *stream, char *out, size_t cap);
+/* One read pair -> SAM: PairAlign::RunAlign's pairing rounds (SortHits4PE + GetPairs, pairs.cpp:29-177) replayed over
+ * the two mates' mode-tagged hit logs, then StringAlignPair / StringAlignUnpair / s_OutHitPair / s_OutHitUnpair
+ * (pairs.cpp:204-485). Mates that both passed QC must have been aligned with BASAL_READ_ALLMODES and
+ * BASAL_STREAM_ALL; if one mate failed QC the other is aligned like an SE read (pairs.cpp:191-196).
+ * Names must already be fixed (FixPairReadName, pairs.cpp:487-507: basal_host_fix_pair_names). stats[9] is
+ * incremented: aligned/unique/multiple for pairs, mate 1, mate 2. */
+typedef struct basal_mate {
+    const char *name, *seq, *qual; /* as FilterReads left them */
+    uint32_t readset, index, max_snp;
+    int qc_failed;
+    const basal_result *res;
+} basal_mate;
+int64_t basal_host_format_pe(const basal_params *p, const basal_ref_t *r, const basal_mate *a, const basal_mate *b,
+                             const basal_hit *stream, char *out, size_t cap, uint32_t stats[9]);
+/* FixPairReadName: truncates both names in place to their common prefix up to its last digit; -1 if they share nothing */
+int basal_host_fix_pair_names(char *name_a, char *name_b);
+
 int64_t basal_host_sam_header(const basal_ref_t *r, const char *cmdline, char *out, size_t cap); /* main.cpp:586-597 */
 
 #ifdef __cplusplus

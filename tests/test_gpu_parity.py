@@ -124,3 +124,30 @@ def test_cli_with_gpu_index(tmp_path):
     assert "seed table (GPU)" in r.stderr
     got = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+@pytest.mark.parametrize("name", H.PE)
+def test_cli_pe_sam_matches_golden(name, tmp_path):
+    """Paired-end: both mates aligned on the GPU (all modes, mode-tagged logs), pairing rounds on the host."""
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    out = tmp_path / "o.sam"
+    r = subprocess.run([BASAL_BIN, "-a", fq, "-b", fq2, "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "3", "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    exp = H.golden_sam(name)
+    if got != exp:
+        g, e = got.splitlines(), exp.splitlines()
+        for i, (x, y) in enumerate(zip(g, e)):
+            if x != y:
+                print("first difference at line", i, "\n got", x[:300], "\n exp", y[:300])
+                break
+    assert got == exp
+
+
+@pytest.mark.parametrize("name", ["pe_rep_r2", "pe_dirty_r1"])
+def test_cli_pe_small_batches(name, tmp_path):
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    out = tmp_path / "o.sam"
+    r = subprocess.run([BASAL_BIN, "-a", fq, "-b", fq2, "-d", fa] + H.MANIFEST[name]["flags"] + ["-Z", "50", "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "".join(l for l in open(out) if not l.startswith("@PG")) == H.golden_sam(name)

@@ -19,6 +19,16 @@ def test_oracle_cli_matches_reference_sam(name, tmp_path):
     assert got == H.golden_sam(name)
 
 
+@pytest.mark.parametrize("name", H.PE)
+def test_oracle_cli_matches_reference_sam_pe(name, tmp_path):
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    out = tmp_path / "o.sam"
+    r = subprocess.run([orc.CLI, "-a", fq, "-b", fq2, "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "1", "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)
+
+
 def test_oracle_threads_same_record_set(tmp_path):
     """-p 4 gives the same records (batch order may differ with >50k reads; here one batch)."""
     name = "ct_basic"

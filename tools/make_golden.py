@@ -103,6 +103,12 @@ PE_FIXTURES = {
     "pe_rep_r2": (["--ref-bp", "400000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--repeat-copies", "150",
                    "--repeat-len", "700", "--max-sub", "3"],
                   ["-M", "C:T", "-S", "1", "-s", "12", "-k", "1e-3", "-r", "2", "-w", "20", "-u"]),
+    "pe_dirty_r1": (["--ref-bp", "400000", "--contigs", "3", "--reads", "400", "-M", "C:T", "--len", "100", "--len-jitter", "40",
+                     "--n-frac", "0.4", "--junk-frac", "0.1", "--repeat-copies", "100", "--repeat-len", "500", "--max-sub", "6"],
+                    ["-M", "C:T", "-S", "3", "-s", "12", "-k", "1e-3", "-u", "-w", "15", "-x", "700"]),
+    "pe_rep_r0": (["--ref-bp", "400000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--repeat-copies", "150",
+                   "--repeat-len", "700", "--max-sub", "3"],
+                  ["-M", "C:T", "-S", "1", "-s", "12", "-k", "1e-3", "-r", "0", "-u", "-w", "20"]),
     "pe_g2_n1": (["--ref-bp", "300000", "--contigs", "2", "--reads", "300", "-M", "A:CGT", "--p-conv", "0.3",
                   "--indel-frac", "0.3"],
                  ["-M", "A:CGT", "-S", "1", "-s", "12", "-g", "2", "-n", "1", "-u"]),
