@@ -50,6 +50,7 @@ struct DevCtx {
     const uint32_t *ref_anchor, *contig_size, *rc_offset;
     uint32_t ncontig;
     const uint32_t *kmer_off, *kmer_nfwd, *locs;
+    const uint64_t *flank_a, *flank_b;  // 32 reference bases after / before each index entry's seed
     uint32_t max_kmer_num;
     uint32_t K, I, max_num_hits, chains, randseed, gap, gap_edge, n_mis, stream_mode, report_repeat_hits;
     const uint8_t *tables;  // alphabet, rev_alphabet, reg_alphabet, alphabet_mread, rev_alphabet_mread
@@ -87,8 +88,19 @@ __device__ __forceinline__ unsigned long long guard_idx(const DevCtx &cx, int ki
 
 struct SeedEnt {  // one (chain, phase) seed of the current mode
     uint32_t off, m, nfwd, h, jj0, pre;  // pre = number of candidates before this seed in the mode's stream
-    uint32_t chain, pad;
+    uint32_t chain, side;                // side: 0 = test the flank after the seed, 1 = the flank before it
+    uint64_t fr, fm, fc;                 // the read's bases / valid mask / convert-to plane opposite that flank
 };
+
+// 32 read bases starting at read position p (may be negative or run past the read: those bases come
+// out with a zero valid mask) from a zero-padded MSB-first plane
+template <int NWT>
+__device__ __forceinline__ uint64_t plane_window(const uint64_t *q, int p) {
+    if (p <= -32 || p >= NWT * 32) return 0;
+    if (p < 0) return q[0] >> (2 * (-p));
+    uint32_t w = (uint32_t)p >> 5, sh = ((uint32_t)p & 31) * 2;
+    return sh ? (q[w] << sh) | (q[w + 1] >> (64 - sh)) : q[w];
+}
 
 template <int NWT>
 struct WaveLds {
@@ -596,7 +608,14 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
             if (lane >= o) inc += v;
         }
         if ((uint32_t)lane < nent) {
-            SeedEnt e = {e_off, e_m, e_nfwd, e_h, e_jj0, inc - e_m, e_chain, 0};
+            // which flank of the seed has more read bases opposite it
+            int n_after = (int)rc.len - (int)(e_h + cx.K), n_before = (int)e_h;
+            n_after = n_after < 0 ? 0 : n_after > 32 ? 32 : n_after;
+            n_before = n_before > 32 ? 32 : n_before;
+            uint32_t side = n_before > n_after;
+            int p0 = side ? (int)e_h - 32 : (int)(e_h + cx.K);
+            SeedEnt e = {e_off, e_m, e_nfwd, e_h, e_jj0, inc - e_m, e_chain, side,
+                         plane_window<NWT>(L.q[e_chain][0], p0), plane_window<NWT>(L.q[e_chain][1], p0), plane_window<NWT>(L.q[e_chain][2], p0)};
             L.ent[lane] = e;
         }
         wave_sync();
@@ -613,12 +632,21 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
             if (active) {
                 uint32_t jj = e.jj0 + (t - e.pre);
                 if (jj >= e.m) jj -= e.m;
-                loc = cx.locs[guard_idx(cx, G_LOCS, (unsigned long long)e.off + jj, cx.nlocs, r)] - e.h;
+                const unsigned long long ei_ = guard_idx(cx, G_LOCS, (unsigned long long)e.off + jj, cx.nlocs, r);
+                loc = cx.locs[ei_] - e.h;
                 if (((unsigned long long)(loc >> 5) + NWT + 4) >= cx.nwords) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
                 strand = jj >= e.nfwd;
-                uint32_t off2 = (loc & 31) * 2;
-                uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
-                mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
+                bool alive = true;
+                if (!GAP) {  // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
+                    uint64_t f = (e.side ? cx.flank_b : cx.flank_a)[ei_];
+                    uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, f) & e.fm);
+                    alive = lb <= st.thr;
+                }
+                if (alive) {
+                    uint32_t off2 = (loc & 31) * 2;
+                    uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
+                    mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
+                }
             }
             uint64_t act = __ballot(active);
             uint64_t ung_pending = act, gap_pending = GAP ? act : 0;
@@ -725,8 +753,18 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
     if (lane0(lane)) cx.results[r] = res;
 }
 
+// Resident waves per SIMD the register allocator is held to (= 256-thread blocks per CU). The kernel is
+// bound by dependent memory round trips per read, so throughput ~ resident waves / per-read latency.
+#ifndef WORK_CHUNK
+#define WORK_CHUNK 8
+#endif
+// Measured on the bench workload (NWT=4, no gap): 100 / 126 / 133 Mreads/s at 4 / 6 / 8 waves per SIMD -- the few
+// registers spilled to scratch at 64 VGPRs cost less than the extra waves bring. Longer reads keep more planes and
+// bitmaps in registers and get fewer waves.
+constexpr int waves_per_simd(int nwt, bool gap) { return nwt == 4 ? (gap ? 6 : 8) : nwt == 8 ? (gap ? 3 : 5) : (gap ? 2 : 3); }
+
 template <int NWT, bool NEWRULE, bool GAP>
-__global__ __launch_bounds__(256) void align_kernel(DevCtx cx) {
+__global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(DevCtx cx) {
     __shared__ uint8_t s_tab[5 * 256];
     __shared__ WaveLds<NWT> s_w[4];
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
@@ -739,17 +777,24 @@ __global__ __launch_bounds__(256) void align_kernel(DevCtx cx) {
     }
     wave_sync();
     basal_hit *log = cx.scratch + (size_t)(blockIdx.x * 4 + wv) * cx.scratch_per_wave;
-    // every wave leaves this loop: the queue head only grows, and the iteration bound below is a
-    // watchdog against an internal error (a wave cannot legitimately take more than n reads)
+    // Work queue: a wave takes WORK_CHUNK consecutive reads per atomic. One atomic per read would cap the
+    // whole GPU at the rate a single memory word can be incremented (~88 M/s measured on MI355X; the
+    // kernel ran at exactly that ceiling, independent of occupancy, before reads were taken in chunks).
+    // Every wave leaves this loop: the queue head only grows, and the iteration bound is a watchdog
+    // against an internal error (a wave cannot legitimately take more than n reads).
     for (uint32_t iter = 0;; iter++) {
         // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
         if (__ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(__ballot(1)), 0, iter); break; }
-        uint32_t r = 0;
-        if (lane0(lane)) r = atomicAdd(cx.work_counter, 1u);
-        r = rfl(r);
-        if (r >= cx.n) break;
-        if (iter > cx.n) { guard_idx(cx, G_WATCHDOG, iter, 0, r); break; }
-        process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, lane);
+        uint32_t base = 0;
+        if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)WORK_CHUNK);
+        base = rfl(base);
+        if (base >= cx.n) break;
+        if (iter > cx.n) { guard_idx(cx, G_WATCHDOG, iter, 0, base); break; }
+        const uint32_t end = base + WORK_CHUNK < cx.n ? base + WORK_CHUNK : cx.n;
+        for (uint32_t r = base; r < end; r++) {
+            if (__ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x30000u | (uint32_t)__popcll(__ballot(1)), 0, r); break; }
+            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, lane);
+        }
     }
 }
 
@@ -813,7 +858,7 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
-    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_tables); hipFree(c->d_scratch);
+    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_flank_b); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -868,6 +913,8 @@ extern "C" int basal_core_set_index(basal_core_t *c, const uint32_t *kmer_off, c
     if (nlocs) HIP_TRY(hipMemcpy(c->d_locs, locs, nlocs * 4, hipMemcpyHostToDevice));
     c->nlocs = nlocs;
     c->max_kmer_num = max_kmer_num;
+    if (!c->have_ref) { g_err = "set_index: stage the reference first (basal_core_set_reference)"; return BASAL_ESTATE; }
+    if (int rc = basal_build_flanks(c)) return rc;
     c->have_index = true;
     return BASAL_OK;
 }
@@ -900,11 +947,7 @@ extern "C" float basal_core_last_kernel_ms(basal_core_t *c) {
 static int ensure_launch_geometry(basal_core *c) {
     if (c->grid) return BASAL_OK;
     uint32_t cus = (uint32_t)c->prop.multiProcessorCount;
-    const char *env = getenv("BASAL_BLOCKS_PER_CU");
-    uint32_t per_cu = env ? (uint32_t)atoi(env) : 4;
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    c->grid = cus * per_cu;
+    c->grid = cus * 8;  // scratch for the largest grid any instantiation uses (8 blocks of 4 waves per CU)
     HIP_TRY(hipMalloc(&c->d_scratch, (size_t)c->grid * 4 * c->scratch_per_wave * sizeof(basal_hit)));
     return BASAL_OK;
 }
@@ -913,7 +956,7 @@ extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_
     if (!c) return BASAL_EINVAL;
     int rc = ensure_launch_geometry(c);
     if (rc) return rc;
-    if (blocks) *blocks = c->grid;
+    if (blocks) *blocks = c->last_grid ? c->last_grid : c->grid;
     if (threads) *threads = 256;
     if (lds_bytes) {
         int nwt = c->nwt ? c->nwt : 4;
@@ -953,6 +996,7 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     cx.xref[0] = c->d_xref[0]; cx.xref[1] = c->d_xref[1];
     cx.ref_anchor = c->d_anchor; cx.contig_size = c->d_size; cx.rc_offset = c->d_rcoff; cx.ncontig = c->ncontig;
     cx.kmer_off = c->d_koff; cx.kmer_nfwd = c->d_knfwd; cx.locs = c->d_locs; cx.max_kmer_num = c->max_kmer_num;
+    cx.flank_a = c->d_flank_a; cx.flank_b = c->d_flank_b;
     cx.K = c->p.seed_size; cx.I = c->p.index_interval; cx.max_num_hits = c->p.max_num_hits; cx.chains = c->p.chains;
     cx.randseed = c->p.randseed; cx.gap = c->p.gap; cx.gap_edge = c->p.gap_edge; cx.n_mis = c->p.n_mis;
     cx.stream_mode = (uint32_t)stream_mode; cx.report_repeat_hits = c->p.report_repeat_hits;
@@ -969,8 +1013,13 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
     cx.guard = c->d_counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
-    uint32_t grid = c->grid;
-    uint32_t need = (n + 3) / 4;
+    const char *env = getenv("BASAL_BLOCKS_PER_CU");
+    uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;
+    c->last_grid = grid;
+    uint32_t need = (n + 4 * WORK_CHUNK - 1) / (4 * WORK_CHUNK);
     if (grid > need) grid = need;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
     static const bool dbg = getenv("BASAL_DEBUG") != nullptr;

@@ -14,6 +14,7 @@ struct basal_core {
     uint32_t *d_anchor = nullptr, *d_size = nullptr, *d_rcoff = nullptr;
     uint32_t ncontig = 0;
     uint32_t *d_koff = nullptr, *d_knfwd = nullptr, *d_locs = nullptr;
+    uint64_t *d_flank_a = nullptr, *d_flank_b = nullptr;  // per index entry: the 32 reference bases after / before the seed
     uint64_t nlocs = 0;
     uint32_t total_kmers = 0, max_kmer_num = 0;
     bool have_ref = false, have_index = false;
@@ -22,7 +23,7 @@ struct basal_core {
     basal_hit *d_scratch = nullptr;
     uint32_t scratch_per_wave = 0;
     unsigned int *d_counter = nullptr;  // [0] work queue head, [1..24] guard ledger
-    uint32_t grid = 0;
+    uint32_t grid = 0, last_grid = 0;
     int nwt = 0;
     // staging for the host-buffer entry point
     uint8_t *d_bases = nullptr; size_t cap_bases = 0;
@@ -35,3 +36,5 @@ struct basal_core {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, timed = false;
 };
+
+int basal_build_flanks(basal_core *c);  // basal_index.hip: fills d_flank_a/d_flank_b from the staged reference + index

@@ -71,7 +71,46 @@ __global__ __launch_bounds__(256) void split_counts(const uint32_t *__restrict__
     } else if (k == total_kmers) koff[k] = nlocs;
 }
 
+// Flank words: for every index entry the 32 reference bases that follow its seed and the 32 that
+// precede it, copied from the packed strand it lies on. The align kernel tests a candidate's flank
+// against the read with one XOR/AND/popcount on the COALESCED location stream; the test can only
+// under-count mismatches, so a candidate it rejects is one CountMismatch (align.h:118-131) rejects
+// too, and only the survivors pay the random reference gather. One thread per k-mer.
+__global__ __launch_bounds__(256) void fill_flanks(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const uint32_t *__restrict__ koff,
+                                                   const uint32_t *__restrict__ knfwd, const uint32_t *__restrict__ locs, uint32_t total_kmers, uint32_t K,
+                                                   uint64_t *__restrict__ fa, uint64_t *__restrict__ fb) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_kmers) return;
+    uint32_t b = koff[k], e = koff[k + 1], nf = knfwd[k];
+    for (uint32_t i = b; i < e; i++) {
+        const uint64_t *x = (i - b) >= nf ? xr : xf;
+        uint32_t g = locs[i];
+        {
+            uint32_t p = g + K, a = (p & 31) * 2;
+            const uint64_t *w = x + (p >> 5);
+            fa[i] = a ? (w[0] << a) | (w[1] >> (64 - a)) : w[0];
+        }
+        {
+            uint32_t p = g - 32, a = (p & 31) * 2;
+            const uint64_t *w = x + (p >> 5);
+            fb[i] = a ? (w[0] << a) | (w[1] >> (64 - a)) : w[0];
+        }
+    }
+}
+
 }  // namespace
+
+int basal_build_flanks(basal_core *c) {
+    hipFree(c->d_flank_a); hipFree(c->d_flank_b);
+    c->d_flank_a = c->d_flank_b = nullptr;
+    HIP_TRYI(hipMalloc(&c->d_flank_a, (c->nlocs + 64) * 8));
+    HIP_TRYI(hipMalloc(&c->d_flank_b, (c->nlocs + 64) * 8));
+    hipLaunchKernelGGL(fill_flanks, dim3((c->total_kmers + 255) / 256), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], c->d_koff, c->d_knfwd, c->d_locs,
+                       c->total_kmers, c->p.seed_size, c->d_flank_a, c->d_flank_b);
+    HIP_TRYI(hipGetLastError());
+    HIP_TRYI(hipDeviceSynchronize());
+    return BASAL_OK;
+}
 
 extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, uint64_t nblocks, uint32_t *max_kmer_num_out) {
     if (!c || (!blocks && nblocks)) { set_error("build_index: null argument"); return BASAL_EINVAL; }
@@ -172,6 +211,7 @@ extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, u
     }
     cleanup();
 #undef TRYC
+    if (int rc = basal_build_flanks(c)) return rc;
     c->have_index = true;
     if (max_kmer_num_out) *max_kmer_num_out = c->max_kmer_num;
     return BASAL_OK;
