@@ -315,26 +315,33 @@ __device__ void reorder_seed(const DevCtx &cx, WaveLds<NWT> &L, const ReadCtx &r
 }
 
 // ---- candidate scoring ----------------------------------------------------------------------
-// CountMismatch / CountMismatch_new (align.h:118-131, 199-239). Returns the exact mismatch count if
-// it is <= thr, otherwise some value > thr (early exit in word order).
+// CountMismatch / CountMismatch_new (align.h:118-131, 199-239): the exact conversion-tolerant mismatch count
+// (the reference's early exit only saves it work; the caller compares with the threshold).
 template <int NWT, bool NEWRULE>
 __device__ __forceinline__ uint32_t count_mismatch(const uint64_t *__restrict__ s, const uint64_t (*q)[NWT + 1], uint32_t off2, uint32_t nw,
                                                    uint32_t thr, uint32_t ncount) {
-    uint64_t s0 = s[0], s1 = s[1];  // one gather covers the common case (early exit in word 0/1)
+    // All reference words of the alignment are requested before any is used: after the flank pre-filter the
+    // lanes that get here are mostly true hits that need every word, and one round trip beats nw of them.
+    uint64_t sw[NWT + 1];
+#pragma unroll
+    for (int i = 0; i <= NWT; i++) sw[i] = (uint32_t)i < nw ? s[i] : 0;
     uint32_t mm = ncount;
-    {
-        uint64_t rw = q[0][0] >> off2, mw = q[1][0] >> off2, cw = NEWRULE ? q[2][0] >> off2 : 0;
-        mm += XM64(cmp_word<NEWRULE>(rw, cw, s0) & mw);
-        if (mm > thr || nw <= 1) return mm;
-    }
-#pragma unroll 1
-    for (uint32_t i = 1; i < nw; i++) {
-        uint64_t si = i == 1 ? s1 : s[i];
-        uint64_t rw = ((q[0][i - 1] << 1) << (63 - off2)) | (q[0][i] >> off2);
-        uint64_t mw = ((q[1][i - 1] << 1) << (63 - off2)) | (q[1][i] >> off2);
-        uint64_t cw = NEWRULE ? ((q[2][i - 1] << 1) << (63 - off2)) | (q[2][i] >> off2) : 0;
-        mm += XM64(cmp_word<NEWRULE>(rw, cw, si) & mw);
-        if (mm > thr) return mm;
+    (void)thr;
+#pragma unroll
+    for (int i = 0; i <= NWT; i++) {
+        if ((uint32_t)i < nw) {
+            uint64_t rw, mw, cw = 0;
+            if (i == 0) {
+                rw = q[0][0] >> off2;
+                mw = q[1][0] >> off2;
+                if (NEWRULE) cw = q[2][0] >> off2;
+            } else {
+                rw = ((q[0][i - 1] << 1) << (63 - off2)) | (q[0][i] >> off2);
+                mw = ((q[1][i - 1] << 1) << (63 - off2)) | (q[1][i] >> off2);
+                if (NEWRULE) cw = ((q[2][i - 1] << 1) << (63 - off2)) | (q[2][i] >> off2);
+            }
+            mm += XM64(cmp_word<NEWRULE>(rw, cw, sw[i]) & mw);
+        }
     }
     return mm;
 }
@@ -450,11 +457,17 @@ __device__ __forceinline__ uint64_t hit_key(uint32_t contig, uint32_t loc, bool 
 template <int NWT>
 __device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t loc, uint32_t strand,
                             uint32_t chain, uint32_t w, uint32_t mode, int gap_size, uint32_t gap_pos, int lane) {
+    // int2hit's binary search over ref_anchor (align.cpp:325-329), 64 probes per step: the largest
+    // contig index whose anchor is <= loc (0 if none) -- one memory round trip for up to 64 contigs
     uint32_t left = 0, right = cx.ncontig;
-    while (left < right - 1) {
-        uint32_t mid = (left + right) / 2;
-        if (loc >= cx.ref_anchor[mid]) left = mid;
-        else right = mid;
+    while (right - left > 1) {
+        uint32_t span = right - left, stride = (span + 63) / 64;
+        uint32_t idx = left + (uint32_t)lane * stride;
+        bool le = idx < right && cx.ref_anchor[idx] <= loc;
+        uint32_t k = (uint32_t)__popcll(__ballot(le));  // probes are ascending, so the true ones form a prefix
+        if (k == 0) { right = left + 1; break; }
+        left = left + (k - 1) * stride;
+        right = left + stride < right ? left + stride : right;
     }
     uint32_t chr = (left * 2 + strand) & 0x3FFFF;
     uint32_t l = loc - cx.ref_anchor[left];
