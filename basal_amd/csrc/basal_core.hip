@@ -102,6 +102,9 @@ __device__ __forceinline__ uint64_t plane_window(const uint64_t *q, int p) {
     return sh ? (q[w] << sh) | (q[w + 1] >> (64 - sh)) : q[w];
 }
 
+// Param::profile[j][i] (param.cpp:70-74), one copy per workgroup instead of an integer division per use
+__shared__ uint16_t s_prof[16][16];
+
 template <int NWT>
 struct WaveLds {
     static constexpr int MAXPOS = NWT * 32;
@@ -148,6 +151,31 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
     }
     return v;
 }
+
+// Reductions / scans over lanes 0..15 with DPP row shifts (4 VALU steps instead of 6 ds_bpermute round trips).
+// row_shr:n = dpp_ctrl 0x110|n: lane i reads lane i-n of its 16-lane row; lanes without a source keep `old`.
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x110 | N, 0xf, 0xf, false);
+}
+// inclusive prefix sum within each 16-lane row
+__device__ __forceinline__ uint32_t row16_scan_add(uint32_t v) {
+    v += dpp_row_shr<1>(0, v);
+    v += dpp_row_shr<2>(0, v);
+    v += dpp_row_shr<4>(0, v);
+    v += dpp_row_shr<8>(0, v);
+    return v;
+}
+// min / sum of lanes 0..15, broadcast to the whole wave
+__device__ __forceinline__ uint32_t row16_min(uint32_t v) {
+    uint32_t t;
+    t = dpp_row_shr<1>(v, v); v = t < v ? t : v;
+    t = dpp_row_shr<2>(v, v); v = t < v ? t : v;
+    t = dpp_row_shr<4>(v, v); v = t < v ? t : v;
+    t = dpp_row_shr<8>(v, v); v = t < v ? t : v;
+    return rdlane(v, 15);
+}
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v) { return rdlane(row16_scan_add(v), 15); }
 
 // bit j of x -> bit 2j
 __device__ __forceinline__ uint64_t spread32(uint32_t x32) {
@@ -258,7 +286,7 @@ template <int NWT>
 __device__ __forceinline__ uint32_t count_seeds(const DevCtx &cx, const WaveLds<NWT> &L, int c, uint32_t n, uint32_t start) {
     uint32_t total = 0, k = 0;
     for (uint32_t i = 0; i < cx.I; i++) {
-        uint32_t pos = profile(n, i, cx.K, cx.I) + start - i;
+        uint32_t pos = s_prof[n & 15][i] + start - i;
         pos = pos < (uint32_t)WaveLds<NWT>::MAXPOS ? pos : (uint32_t)WaveLds<NWT>::MAXPOS - 1;
         uint32_t s = L.seed[c][pos];
         if (s >> 31) k = 12;
@@ -273,7 +301,7 @@ __device__ uint32_t best_start_offset(const DevCtx &cx, const WaveLds<NWT> &L, c
     uint32_t best = 0xffffffffu, so = inherited;
     for (uint32_t st = 0; st < rc.ii; st++) {
         uint32_t cs = (uint32_t)lane < rc.nseg ? count_seeds(cx, L, c, (uint32_t)lane, st) : 0;
-        uint32_t tt = wave_sum(cs);
+        uint32_t tt = row16_sum(cs);  // nseg <= 16
         if (tt < best) { best = tt; so = st; }
     }
     return so;
@@ -295,7 +323,7 @@ __device__ void reorder_seed(const DevCtx &cx, WaveLds<NWT> &L, const ReadCtx &r
             uint32_t cand = start + lane;
             bool valid = cand <= end && lane < 16;
             uint32_t tt = valid ? count_seeds(cx, L, c, ptr, cand) : 0xffffffffu;
-            uint32_t m = wave_min(tt);
+            uint32_t m = row16_min(tt);  // valid lanes are < 16
             uint32_t pick = start;
             if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)__ballot(valid && tt == m)) - 1;
             if (lane0(lane)) L.start_arr[c][ptr] = (uint8_t)pick;
@@ -592,16 +620,17 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
     st.key0 = st.key1 = ~0ULL;
     const uint32_t rnd = myrand(rc.index, cx.randseed);
     const uint32_t nent = 2 * cx.I;
+    const uint32_t ent_c = (uint32_t)lane >= cx.I ? 1u : 0u, ent_i = (uint32_t)lane >= cx.I ? (uint32_t)lane - cx.I : (uint32_t)lane;  // lane < 2I
 
     bool done = false;
     for (uint32_t mode = 0; mode < rc.nseg && !done; mode++) {
         // the seeds of this mode, chain-major then phase (the order SnpAlign visits them, align.cpp:275-279)
         uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0;
         if ((uint32_t)lane < nent) {
-            uint32_t c = (uint32_t)lane / cx.I, i = (uint32_t)lane % cx.I;
+            const uint32_t c = ent_c, i = ent_i;
             if (rc.on(c)) {
                 uint32_t seg = L.order[c][mode];
-                uint32_t pos = profile(seg & 15, i, cx.K, cx.I) + L.start_arr[c][seg & 15] - i;
+                uint32_t pos = s_prof[seg & 15][i] + L.start_arr[c][seg & 15] - i;
                 pos = (uint32_t)guard_idx(cx, G_LDSPOS, pos, WaveLds<NWT>::MAXPOS, r);
                 uint32_t sd = L.seed[c][pos] & 0x7fffffffu, m = L.cnt[c][pos];
                 if (sd >= cx.total_kmers) sd = (uint32_t)guard_idx(cx, G_KMER2, 0x80000000u | pos | (seg << 16) | (c << 24) | (mode << 26), 0, r);
@@ -616,10 +645,12 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
             }
         }
         uint32_t inc = e_m;  // inclusive prefix sum over lanes 0..nent-1
-        for (int o = 1; o < 32; o <<= 1) {
-            uint32_t v = __shfl_up(inc, o);
-            if (lane >= o) inc += v;
-        }
+        if (nent <= 16) inc = row16_scan_add(inc);
+        else
+            for (int o = 1; o < 32; o <<= 1) {
+                uint32_t v = __shfl_up(inc, o);
+                if (lane >= o) inc += v;
+            }
         if ((uint32_t)lane < nent) {
             // which flank of the seed has more read bases opposite it
             int n_after = (int)rc.len - (int)(e_h + cx.K), n_before = (int)e_h;
@@ -781,6 +812,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     __shared__ uint8_t s_tab[5 * 256];
     __shared__ WaveLds<NWT> s_w[4];
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
+    s_prof[threadIdx.x >> 4][threadIdx.x & 15] = (uint16_t)profile(threadIdx.x >> 4, threadIdx.x & 15, cx.K, cx.I);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     WaveLds<NWT> &L = s_w[wv];
