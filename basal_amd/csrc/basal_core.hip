@@ -77,11 +77,24 @@ struct DevCtx {
 
 enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 5, G_KMER2 = 6, G_WATCHDOG = 7 };
 
+// Cold kernel arguments are re-read from the kernarg segment where they are used (scalar loads through the
+// constant cache) instead of being kept live in SGPRs for the whole kernel, where they were spilled to VGPR
+// lanes (v_writelane/v_readlane are VALU work, and VALU issue is what bounds this kernel).
+typedef const DevCtx __attribute__((address_space(4))) *ColdCtxPtr;
+__device__ __forceinline__ ColdCtxPtr cold_ctx() {
+    ColdCtxPtr p = (ColdCtxPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define COLD(f) (cold_ctx()->f)
+// a pointer argument fetched that way: tell the compiler it points to global memory (otherwise: flat_load)
+#define COLDP(T, f) ((T *)(T __attribute__((address_space(1))) *)(cold_ctx()->f))
+
 __device__ __forceinline__ unsigned long long guard_idx(const DevCtx &cx, int kind, unsigned long long idx, unsigned long long lim, uint32_t r) {
     if (idx < lim) return idx;
-    if (atomicAdd(&cx.guard[kind], 1u) == 0) {
-        cx.guard[8 + kind] = (unsigned int)idx;
-        cx.guard[16 + kind] = r;
+    if (atomicAdd(&COLDP(unsigned int, guard)[kind], 1u) == 0) {
+        COLDP(unsigned int, guard)[8 + kind] = (unsigned int)idx;
+        COLDP(unsigned int, guard)[16 + kind] = r;
     }
     return 0;
 }
@@ -233,7 +246,7 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
         for (uint32_t b = 0; b <= (uint32_t)NWT / 2; b++) {
             uint32_t pos = b * 64 + lane;
             uint32_t ch = 0;
-            if (b < nblk && pos < rc.len) ch = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + (c ? rc.len - 1 - pos : pos), cx.nbases, rc.rno)];
+            if (b < nblk && pos < rc.len) ch = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + (c ? rc.len - 1 - pos : pos), COLD(nbases), rc.rno)];
             uint64_t a0, a1, v0, v1, m0, m1;
             uint32_t valid = rg[ch];
             pack_codes(al[ch], a0, a1);
@@ -249,7 +262,7 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
     if (!rc.on(0)) {  // count N's when only chain 1 is packed (CountNs, align.cpp:40-47)
         for (uint32_t b = 0; b < nblk; b++) {
             uint32_t pos = b * 64 + lane;
-            uint32_t ch = pos < rc.len ? cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + pos, cx.nbases, rc.rno)] : 'A';
+            uint32_t ch = pos < rc.len ? cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + pos, COLD(nbases), rc.rno)] : 'A';
             ncnt += __popcll(__ballot(!tab[512 + ch]));
         }
     }
@@ -270,7 +283,7 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
                 }
                 uint32_t s = (uint32_t)(a >> (64 - kbits)), sb = (uint32_t)(b >> (64 - kbits));
                 uint32_t full = kbits == 32 ? 0xFFFFFFFFu : ((1u << kbits) - 1);
-                sd = (uint32_t)guard_idx(cx, G_KMER, XT(s), cx.total_kmers, rc.rno);
+                sd = (uint32_t)guard_idx(cx, G_KMER, XT(s), COLD(total_kmers), rc.rno);
                 ct = cx.kmer_off[sd + 1] - cx.kmer_off[sd];
                 if ((~sb) & full) sd |= 0x80000000u;
             }
@@ -487,26 +500,26 @@ __device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, bas
                             uint32_t chain, uint32_t w, uint32_t mode, int gap_size, uint32_t gap_pos, int lane) {
     // int2hit's binary search over ref_anchor (align.cpp:325-329), 64 probes per step: the largest
     // contig index whose anchor is <= loc (0 if none) -- one memory round trip for up to 64 contigs
-    uint32_t left = 0, right = cx.ncontig;
+    uint32_t left = 0, right = COLD(ncontig);
     while (right - left > 1) {
         uint32_t span = right - left, stride = (span + 63) / 64;
         uint32_t idx = left + (uint32_t)lane * stride;
-        bool le = idx < right && cx.ref_anchor[idx] <= loc;
+        bool le = idx < right && COLDP(const uint32_t, ref_anchor)[idx] <= loc;
         uint32_t k = (uint32_t)__popcll(__ballot(le));  // probes are ascending, so the true ones form a prefix
         if (k == 0) { right = left + 1; break; }
         left = left + (k - 1) * stride;
         right = left + stride < right ? left + stride : right;
     }
     uint32_t chr = (left * 2 + strand) & 0x3FFFF;
-    uint32_t l = loc - cx.ref_anchor[left];
+    uint32_t l = loc - COLDP(const uint32_t, ref_anchor)[left];
     uint32_t gp = gap_pos & 0x1FF;
     if (strand) {
-        l = cx.rc_offset[chr >> 1] - rc.len - l;
+        l = COLDP(const uint32_t, rc_offset)[chr >> 1] - rc.len - l;
         gp = (uint32_t)((int)rc.len + (gap_size < 0 ? gap_size : 0) - (int)gp) & 0x1FF;
         l -= (uint32_t)gap_size;
     }
     if ((int)l < 0) return 0;
-    if (l + rc.len > cx.contig_size[chr >> 1]) return 0;
+    if (l + rc.len > COLDP(const uint32_t, contig_size)[chr >> 1]) return 0;
     uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
     bool dup = ((uint32_t)lane < st.nlog && st.key0 == key) || ((uint32_t)lane + 64 < st.nlog && st.key1 == key);
     if (__ballot(dup)) return 0;
@@ -519,7 +532,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, bas
         if (__ballot(d)) return 0;
     }
     uint32_t n = st.nlog;
-    if (n < cx.scratch_per_wave) {
+    if (n < COLD(scratch_per_wave)) {
         if (lane0(lane)) {
             basal_hit h;
             h.loc = l; h.chr = chr; h.gap_size = (int8_t)gap_size; h.strand = (uint8_t)(((strand << 1) | chain) & 3);
@@ -538,7 +551,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, bas
         tot = a + L.nhit[chain ^ 1][w];
     }
     wave_sync();
-    if (tot >= cx.max_num_hits) {
+    if (tot >= COLD(max_num_hits)) {
         if (w == 0) return 1;
         st.thr = w - 1;
     }
@@ -575,15 +588,15 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
     res.best_level = 0xFF;
     if (rd.len == 0 || rd.len > (uint32_t)NWT * 32 || rd.len > BASAL_MAXREADLEN) {
         res.status = BASAL_READ_SKIPPED;
-        if (lane0(lane)) cx.results[r] = res;
+        if (lane0(lane)) COLDP(basal_result, results)[r] = res;
         return;
     }
     ReadCtx rc;
     uint32_t slot = rd.readset == 2 ? 1 : 0;
-    uint32_t so0 = cx.carry[slot][0], so1 = cx.carry[slot][1];
-    const bool stale = rd.stale_idx < cx.nstale;
+    uint32_t so0 = COLD(carry)[slot][0], so1 = COLD(carry)[slot][1];
+    const bool stale = rd.stale_idx < COLD(nstale);
     if (stale) {  // inherit xseed_start_offset from an earlier read of this batch (align.cpp:475-480)
-        uint32_t srcno = cx.stales[rd.stale_idx].src;
+        uint32_t srcno = COLDP(const basal_stale, stales)[rd.stale_idx].src;
         if (srcno < r) {
             basal_read src = cx.reads[srcno];
             rc.rno = r;
@@ -598,8 +611,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
         if (lane < 30) {
             uint32_t c = (uint32_t)lane / 15, j = (uint32_t)lane % 15, pos = rc.npos + j;
             if (rc.on(c) && pos < (uint32_t)WaveLds<NWT>::MAXPOS) {
-                uint32_t sd = cx.stales[rd.stale_idx].overlay[c][j];
-                sd = (sd & 0x80000000u) | (uint32_t)guard_idx(cx, G_STALE, sd & 0x7fffffffu, cx.total_kmers, r);
+                uint32_t sd = COLDP(const basal_stale, stales)[rd.stale_idx].overlay[c][j];
+                sd = (sd & 0x80000000u) | (uint32_t)guard_idx(cx, G_STALE, sd & 0x7fffffffu, COLD(total_kmers), r);
                 L.seed[c][pos] = sd;
                 sd &= 0x7fffffffu;
                 L.cnt[c][pos] = cx.kmer_off[sd + 1] - cx.kmer_off[sd];
@@ -633,7 +646,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                 uint32_t pos = s_prof[seg & 15][i] + L.start_arr[c][seg & 15] - i;
                 pos = (uint32_t)guard_idx(cx, G_LDSPOS, pos, WaveLds<NWT>::MAXPOS, r);
                 uint32_t sd = L.seed[c][pos] & 0x7fffffffu, m = L.cnt[c][pos];
-                if (sd >= cx.total_kmers) sd = (uint32_t)guard_idx(cx, G_KMER2, 0x80000000u | pos | (seg << 16) | (c << 24) | (mode << 26), 0, r);
+                if (sd >= COLD(total_kmers)) sd = (uint32_t)guard_idx(cx, G_KMER2, 0x80000000u | pos | (seg << 16) | (c << 24) | (mode << 26), 0, r);
                 if (m != 0 && m <= cx.max_kmer_num) {
                     e_m = m;
                     e_off = cx.kmer_off[sd];
@@ -676,9 +689,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
             if (active) {
                 uint32_t jj = e.jj0 + (t - e.pre);
                 if (jj >= e.m) jj -= e.m;
-                const unsigned long long ei_ = guard_idx(cx, G_LOCS, (unsigned long long)e.off + jj, cx.nlocs, r);
+                const unsigned long long ei_ = guard_idx(cx, G_LOCS, (unsigned long long)e.off + jj, COLD(nlocs), r);
                 loc = cx.locs[ei_] - e.h;
-                if (((unsigned long long)(loc >> 5) + NWT + 4) >= cx.nwords) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
+                if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
                 strand = jj >= e.nfwd;
                 bool alive = true;
                 if (!GAP) {  // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
@@ -764,16 +777,16 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
         uint32_t j = sum == 1 ? 0 : rnd % sum;
         uint32_t idx = j < nh ? find_kth(log, st.nlog, ii, 0, j, lane) : find_kth(log, st.nlog, ii, 1, j - nh, lane);
         if (idx != 0xffffffffu) res.best = log[idx];
-        if (cx.stream_mode == BASAL_STREAM_BEST || cx.stream_mode == BASAL_STREAM_ALL) {
-            uint32_t need = cx.stream_mode == BASAL_STREAM_ALL ? st.nlog : sum;
+        if (COLD(stream_mode) == BASAL_STREAM_BEST || COLD(stream_mode) == BASAL_STREAM_ALL) {
+            uint32_t need = COLD(stream_mode) == BASAL_STREAM_ALL ? st.nlog : sum;
             unsigned long long first = 0;
-            if (lane0(lane)) first = atomicAdd(cx.stream_used, (unsigned long long)need);
+            if (lane0(lane)) first = atomicAdd(COLDP(unsigned long long, stream_used), (unsigned long long)need);
             first = ((unsigned long long)rfl((uint32_t)(first >> 32)) << 32) | rfl((uint32_t)first);
             res.stream_first = (uint32_t)first;
             res.stream_n = need;
-            if (first + need > cx.stream_cap) res.status = BASAL_READ_OVERFLOW;
-            else if (cx.stream_mode == BASAL_STREAM_ALL) {
-                for (uint32_t i = lane; i < st.nlog; i += 64) cx.stream[first + i] = log[i];
+            if (first + need > COLD(stream_cap)) res.status = BASAL_READ_OVERFLOW;
+            else if (COLD(stream_mode) == BASAL_STREAM_ALL) {
+                for (uint32_t i = lane; i < st.nlog; i += 64) COLDP(basal_hit, stream)[first + i] = log[i];
             } else {
                 uint32_t outp = 0;
                 for (uint32_t c = 0; c < 2; c++)
@@ -785,16 +798,16 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                             m = h.level == ii && h.chain == c;
                         }
                         uint64_t b = __ballot(m);
-                        if (m) cx.stream[first + outp + (uint32_t)__popcll(b & ((1ULL << lane) - 1))] = h;
+                        if (m) COLDP(basal_hit, stream)[first + outp + (uint32_t)__popcll(b & ((1ULL << lane) - 1))] = h;
                         outp += (uint32_t)__popcll(b);
                     }
             }
         }
-    } else if (cx.stream_mode == BASAL_STREAM_ALL && st.nlog) {
+    } else if (COLD(stream_mode) == BASAL_STREAM_ALL && st.nlog) {
         // hits exist only above read_max_snp_num: cannot happen (levels are <= thr <= max_snp); kept for safety
         res.stream_n = 0;
     }
-    if (lane0(lane)) cx.results[r] = res;
+    if (lane0(lane)) COLDP(basal_result, results)[r] = res;
 }
 
 // Resident waves per SIMD the register allocator is held to (= 256-thread blocks per CU). The kernel is
@@ -821,7 +834,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
             for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
     }
     wave_sync();
-    basal_hit *log = cx.scratch + (size_t)(blockIdx.x * 4 + wv) * cx.scratch_per_wave;
+    basal_hit *log = cx.scratch + (size_t)(blockIdx.x * 4 + wv) * COLD(scratch_per_wave);
     // Work queue: a wave takes WORK_CHUNK consecutive reads per atomic. One atomic per read would cap the
     // whole GPU at the rate a single memory word can be incremented (~88 M/s measured on MI355X; the
     // kernel ran at exactly that ceiling, independent of occupancy, before reads were taken in chunks).
