@@ -177,45 +177,22 @@ def main():
     cpu = None
     roof = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        import oracle as orc
+        import oracle_bridge
         ns = min(args.cpu_sample, args.batch * args.steps)
-        OL = orc.lib()
-        tk = 3 ** params.c.seed_size
-        off, nfwd, locs, mk2 = core.get_index(tk)
-        out["config"]["index_entries"] = int(len(locs))
-        n_tot = np.diff(off.astype(np.uint64)).astype(np.uint32)
-        off64 = off.astype(np.uint64)
-        op = orc.make_param(flags)
-        op.max_kmer_num = mk2
-        names = (C.c_char_p * len(sizes))(*[n.encode() for n in G.names])
-        oref = OL.orc_ref_from_arrays(len(sizes), names, sizes.ctypes.data, words[0].ctypes.data, words[1].ctypes.data, len(words[0]), tk,
-                                      n_tot.ctypes.data, nfwd.ctypes.data, off64.ctypes.data, locs.ctypes.data, len(locs))
+        ob = oracle_bridge.OracleOnIndex(core, params, flags, G.names, sizes, words)
+        out["config"]["index_entries"] = int(len(ob.locs))
         first = args.warmup * args.batch
         sb = d_bases[first * read_len:(first + ns) * read_len].cpu().numpy()
         sd = descs[first:first + ns]
-        seq_off = (sd["seq_off"] - first * read_len).astype(np.uint32)
-        lens = sd["len"].astype(np.uint16)
-        idx = sd["index"].astype(np.uint32)
-        msn = sd["max_snp"].astype(np.uint8)
-
-        class orc_best(C.Structure):
-            _fields_ = [(n, C.c_uint32) for n in ("best_level", "n_hit", "n_chit", "chr", "loc")] + [("gap_size", C.c_int32), ("gap_pos", C.c_uint32), ("chain", C.c_uint32)]
-        best = np.zeros(ns, dtype=np.dtype([("best_level", "<u4"), ("n_hit", "<u4"), ("n_chit", "<u4"), ("chr", "<u4"), ("loc", "<u4"),
-                                            ("gap_size", "<i4"), ("gap_pos", "<u4"), ("chain", "<u4")]))
-        cnt = orc.orc_counters()
-        secs = C.c_double()
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-        OL.orc_align_batch_mt.argtypes = [C.POINTER(orc.orc_param), C.POINTER(orc.orc_ref), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_uint32, C.c_int, C.c_void_p, C.POINTER(orc.orc_counters), C.POINTER(C.c_double)]
-        OL.orc_align_batch_mt(C.byref(op), oref, sb.ctypes.data, seq_off.ctypes.data, lens.ctypes.data, idx.ctypes.data, msn.ctypes.data, ns, threads,
-                              best.ctypes.data, C.byref(cnt), C.byref(secs))
-        gpu = timed[:ns]
-        same = ((gpu["best_level"].astype(np.uint32) == (best["best_level"] & 0xFF)) & (gpu["n_hit"] == best["n_hit"]) & (gpu["n_chit"] == best["n_chit"]))
-        hit = best["best_level"] != 0xFF
-        same &= ~hit | ((gpu["best"]["loc"] == best["loc"]) & (gpu["best"]["chr"] == best["chr"]) & (gpu["best"]["chain"] == best["chain"]))
-        nbad = int((~same).sum())
-        if nbad:
-            raise SystemExit("bench: %d of %d sampled reads differ between the GPU path and the CPU oracle -- number withheld" % (nbad, ns))
+        best, cnt, secs_v = ob.align(sb, sd["seq_off"] - first * read_len, sd["len"], sd["index"], sd["max_snp"], threads)
+        bad = oracle_bridge.differing(timed[:ns], best)
+        if len(bad):
+            raise SystemExit("bench: %d of %d sampled reads differ between the GPU path and the CPU oracle -- number withheld" % (len(bad), ns))
+
+        class _S:
+            value = secs_v
+        secs = _S()
         Bread = (4 * cnt.hdr_lookups + 16 * cnt.seed_lookups + 4 * cnt.candidates + 8 * cnt.ref_words + cnt.read_bytes + 16 * cnt.hit_records) / ns
         cpu = {"value": ns / secs.value / 1e6, "unit": "Mreads/s", "cores": threads, "kind": "port",
                "sample": "%d reads of the timed workload, same index; GPU results identical to the oracle on all of them" % ns}

@@ -4,6 +4,13 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime; it has to be the first one loaded into the process (libbasal_amd.so then binds
+# to it). Loading libbasal_amd.so first and torch afterwards leaves torch without a visible device.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,115 @@
+"""At-scale checks on the GPU (genome-scale inputs generated on the device, tools/synth_gpu.py): the
+configs of BASELINE.json that are not the bench line run here as parity cases against the CPU oracle on
+a sample, plus size-independent properties over ALL reads: planted positions are recovered, results
+do not depend on how the reads are batched, and a second run is identical."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import basal_amd as B
+from basal_amd import core as bc
+import harness as H
+
+sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: (rule, flags, read_len, n_reads, p_conv, sub_rate)
+    "c2_ct_g0": ("C:T", ["-M", "C:T", "-S", "1"], 100, 200_000, 0.95, 0.01),
+    "c3_ag_150": ("A:G", ["-M", "A:G", "-S", "1", "-n", "1"], 150, 60_000, 0.9, 0.01),
+    "c4_acgt_g2": ("A:CGT", ["-M", "A:CGT", "-S", "1", "-g", "2"], 100, 60_000, 0.3, 0.01),
+    "c5_tdel": ("T:-", ["-M", "T:-", "-S", "1"], 100, 100_000, 0.0, 0.01),
+    "c5_tdel_pipeline": ("T:-", ["-M", "T:-", "-S", "1", "-n", "1", "-g", "3"], 100, 40_000, 0.0, 0.01),
+}
+
+
+def setup(name, scale=0.02):
+    import torch
+    import synth_gpu
+    rule, flags, rl, n, pconv, sub = CONFIGS[name]
+    dev = torch.device("cuda", 0)
+    p = B.Params(rule, flags)
+    G = synth_gpu.make_genome(p, dev, scale=scale, seed=3)
+    words = [w.cpu().numpy().view(np.uint64) for w in G.words]
+    sizes = np.array(G.sizes, dtype=np.uint32)
+    core = B.Core(p, 0)
+    L = B.lib()
+    bc._check(L.basal_core_set_reference(core.h, words[0].ctypes.data, words[1].ctypes.data, len(words[0]), G.anchors.ctypes.data, sizes.ctypes.data,
+                                         G.rc_offsets.ctypes.data, len(sizes)), "set_reference")
+    mk = C.c_uint32()
+    blocks = np.ascontiguousarray(G.blocks)
+    bc._check(L.basal_core_build_index(core.h, blocks.ctypes.data, len(blocks), C.byref(mk)), "build_index")
+    frm = "ACGT".index(rule[0])
+    tos = [t for t in rule[2:] if t in "ACGT"]
+    to = "ACGT".index(tos[0]) if tos else frm
+    bases, ci, start, rev = synth_gpu.make_reads(G, n, dev, read_len=rl, seed=11, conv_from=frm, conv_to=to, p_conv=pconv if tos else 0.0, sub_rate=sub)
+    hb = bases.cpu().numpy()
+    seq = C.create_string_buffer(b"A" * rl, rl + 2)
+    qual = C.create_string_buffer(b"I" * rl, rl + 2)
+    ms = C.c_uint32()
+    assert L.basal_host_filter_read(C.byref(p.c), seq, qual, C.byref(ms)) == 0
+    descs = np.zeros(n, bc.READ_DTYPE)
+    descs["seq_off"] = np.arange(n, dtype=np.uint64) * rl
+    descs["index"] = np.arange(n, dtype=np.uint32)
+    descs["len"], descs["max_snp"], descs["stale_idx"] = rl, ms.value, B.STALE_NONE
+    return p, flags, G, words, sizes, core, hb, descs, (ci.cpu().numpy(), start.cpu().numpy(), rev.cpu().numpy())
+
+
+def run(core, hb, descs, split=None):
+    n = len(descs)
+    if not split:
+        return core.align_batch(hb, descs)[0]
+    parts = []
+    for b0 in range(0, n, split):
+        parts.append(core.align_batch(hb, descs[b0:b0 + split])[0])
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_matches_oracle_on_sample_and_properties(name):
+    import oracle_bridge
+    p, flags, G, words, sizes, core, hb, descs, (ci, start, rev) = setup(name)
+    n = len(descs)
+    res = run(core, hb, descs)
+    # 1. parity with the CPU oracle on a sample (same index, downloaded from the GPU)
+    ns = 6000 if "g" in "".join(flags) else 15000
+    ob = oracle_bridge.OracleOnIndex(core, p, flags, G.names, sizes, words)
+    sel = np.linspace(0, n - 1, ns).astype(np.int64)
+    rl = int(descs["len"][0])
+    sb = np.concatenate([hb[i * rl:(i + 1) * rl] for i in sel])
+    best, cnt, _ = ob.align(sb, np.arange(ns, dtype=np.uint32) * rl, descs["len"][sel], descs["index"][sel], descs["max_snp"][sel], 8)
+    bad = oracle_bridge.differing(res[sel], best)
+    assert len(bad) == 0, "reads %s differ from the oracle" % sel[bad][:10]
+    # 2. planted truth: a uniquely aligned ungapped read sits where it was sampled from
+    # A:CGT seeds only tolerate the conversion to the base coded 11 (A<->T), so reads whose A's became C
+    # lose seeds and a share of them cannot be placed -- in the reference too (the oracle sample above agrees)
+    assert (res["best_level"] != 0xFF).mean() > (0.75 if name == "c4_acgt_g2" else 0.95)
+    uniq_any = (res["best_level"] != 0xFF) & (res["n_hit"].astype(np.uint32) + res["n_chit"] == 1)
+    # with -g the reference stores an ungapped and a gapped placement of the same locus as two hits, so many
+    # reads count as "multiple" there; without -g nearly every read of this random genome is unique
+    assert uniq_any.mean() > (0.5 if "-g" in flags else 0.95)
+    uniq = uniq_any & (res["best"]["gap_size"] == 0)
+    ok = (res["best"]["chr"] >> 1 == ci) & (res["best"]["loc"] == start)
+    assert ok[uniq].mean() > 0.995
+    # strand bookkeeping: reverse-strand reads of a directional library land on the RC reference strand
+    if "-n" not in flags:
+        assert ((res["best"]["chr"] & 1) == rev)[uniq & ok].all()
+    # 3. batching must not matter (the global read number, not the batch position, feeds myrand)
+    res2 = run(core, hb, descs, split=37_123)
+    assert res.tobytes() == res2.tobytes()
+    # 4. idempotence
+    assert run(core, hb, descs).tobytes() == res.tobytes()
+
+
+def test_read_order_independence():
+    """Results belong to reads, not to slots: aligning a permutation gives the permuted results."""
+    p, flags, G, words, sizes, core, hb, descs, _ = setup("c2_ct_g0", scale=0.01)
+    n = 50_000
+    descs = descs[:n]
+    res = run(core, hb, descs)
+    perm = np.random.default_rng(5).permutation(n)
+    res_p = run(core, hb, descs[perm])
+    assert res_p.tobytes() == res[perm].tobytes()
