@@ -202,7 +202,18 @@ int main(int argc, char **argv) {
         for (uint32_t i = 0; i < maxi && r->pos < r->buf.size(); i++) r->rest_of_line();
         r->index = read_start - 1;
     }
-    FILE *fo = out_file.empty() ? stdout : fopen(out_file.c_str(), "w");
+    // -o x.bam pipes SAM through an external `samtools view -bS -`, like the reference (main.cpp:504-513)
+    bool piped = false;
+    FILE *fo = stdout;
+    if (!out_file.empty()) {
+        if (out_file.size() > 4 && out_file.compare(out_file.size() - 4, 4, ".bam") == 0) {
+            std::string cmd = "samtools view -bS - >" + out_file;
+            fo = popen(cmd.c_str(), "w");
+            piped = fo != nullptr;
+            if (!fo) fprintf(stderr, "unable to creat samtools pipe, writing SAM instead.\n");
+        }
+        if (!piped) fo = fopen(out_file.c_str(), "w");
+    }
     if (!fo) die("failed to open output file (check -o option): " + out_file);
     if (sam_header) {
         std::vector<char> hb(64 + cmdline.size() + 128 * (size_t)basal_host_ref_ncontig(R) + 4096);
@@ -384,7 +395,8 @@ int main(int argc, char **argv) {
         }
     }
     double t4 = now();
-    if (fo != stdout) fclose(fo);
+    if (piped) pclose(fo);
+    else if (fo != stdout) fclose(fo);
     if (verbose >= 1 && !P.pairend) {
         uint32_t tot = ra.index - read_start + 1;
         fprintf(stderr, "[BASAL-MI355X] total reads: %u \ttotal time:  %.2f secs (align %.3f s: GPU batches %.3f s, host QC+SAM %.3f s)\n", tot, t4 - t0, t4 - t3, t_gpu, t_host);

@@ -63,10 +63,15 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    local = local % torch.cuda.device_count()  # (a gloo rehearsal may put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("BASAL_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     flags = ["-M", args.rule, "-S", "1"] + (["-g", str(args.gap)] if args.gap else [])
     params = B.Params(args.rule, flags)
@@ -138,21 +143,28 @@ def main():
         step(i)
     sync_all()
     kernel_ms = []
-    gathered = [torch.empty_like(d_results[args.warmup * args.batch * 32:]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty(args.steps * args.batch * 32, dtype=torch.uint8, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         step(i)
         kernel_ms.append(core.kernel_ms())  # waits for this step's stop event (HIP events on the launch stream)
     bc._check(L.basal_core_sync_check(core.h), "align kernels")
     if world > 1:  # the one collective of the path: per-read results to the rank that writes SAM
-        dist.gather(d_results[args.warmup * args.batch * 32:], gathered, dst=0)
+        dist.gather(d_results[args.warmup * args.batch * 32:].to(gdev), gathered, dst=0)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     reads_timed = args.batch * args.steps * world
+    if world > 1 and rank == 0:  # what rank 0 would hand to the SAM writer: every rank's records, in rank order
+        allres = np.concatenate([np.frombuffer(g.cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE) for g in gathered])
+        assert len(allres) == reads_timed
+        gathered_aligned = int((allres["best_level"] != 0xFF).sum())
+    else:
+        gathered_aligned = None
 
     res = np.frombuffer(d_results.cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE)
     timed = res[args.warmup * args.batch:]
@@ -169,7 +181,7 @@ def main():
                                "(%.2f Gbp, %d contigs, N gaps, planted repeats), reference + seed index resident in HBM, reads resident in HBM"
                                % (args.batch * args.steps // 1_000_000, args.batch, args.rule, args.gap, total_bp / 1e9, len(sizes)),
                    "reads_per_step_per_gpu": args.batch, "genome_bp": total_bp, "index_entries": None, "aligned_frac": aligned / max(1, len(timed)),
-                   "unique_frac": unique / max(1, len(timed)), "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
+                   "unique_frac": unique / max(1, len(timed)), "gathered_aligned_reads": gathered_aligned, "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
                    "index_build_s": round(t_index, 2)},
     }
 
