@@ -118,13 +118,20 @@ __device__ __forceinline__ uint64_t plane_window(const uint64_t *q, int p) {
 // Param::profile[j][i] (param.cpp:70-74), one copy per workgroup instead of an integer division per use
 __shared__ uint16_t s_prof[16][16];
 
-template <int NWT>
+struct SeedEntGap {  // GAP kernels: the read's window opposite the flank BEFORE the seed, and which of its bases lie in the read
+    uint64_t br, bm, bc, bin;
+};
+
+template <int NWT, bool GAP>
 struct WaveLds {
+    static constexpr int NW = NWT;
     static constexpr int MAXPOS = NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
     uint32_t seed[2][MAXPOS];   // XT hash; bit 31: seed window contains a non-ACGT base
     uint32_t cnt[2][MAXPOS];    // index2[seed].n[0]
     SeedEnt ent[32];
+    SeedEntGap entg[GAP ? 32 : 1];
+    uint32_t surv[GAP ? 128 : 1];  // GAP: stream indices of candidates the flank tests could not rule out, in visitation order
     uint16_t nhit[2][16];  // x_cur_n_hit[chain][level]
     uint8_t start_arr[2][16];
     uint8_t order[2][16];
@@ -220,8 +227,9 @@ struct ReadCtx {
 };
 
 // ---- steps 1+2: pack, hash seeds, gather counts --------------------------------------------
-template <int NWT>
-__device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane) {
+template <class LDS>
+__device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane) {
+    constexpr int NWT = LDS::NW;
     rc.len = rd.len;
     rc.index = rd.index;
     const uint32_t rs = rd.readset & 0x7fu;
@@ -272,7 +280,7 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
     const uint32_t kbits = 2 * cx.K;
     for (int c = 0; c < 2; c++) {
         if (!rc.on(c)) continue;
-        for (uint32_t p = lane; p < (uint32_t)WaveLds<NWT>::MAXPOS; p += 64) {
+        for (uint32_t p = lane; p < (uint32_t)LDS::MAXPOS; p += 64) {
             uint32_t sd = 0x80000000u, ct = 0;  // out-of-read positions: "contains N", count 0
             if (p < rc.npos) {
                 uint32_t w = p >> 5, sh = (p & 31) * 2;
@@ -295,12 +303,12 @@ __device__ void prep_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab,
 }
 
 // CountSeeds (align.cpp:526-540)
-template <int NWT>
-__device__ __forceinline__ uint32_t count_seeds(const DevCtx &cx, const WaveLds<NWT> &L, int c, uint32_t n, uint32_t start) {
+template <class LDS>
+__device__ __forceinline__ uint32_t count_seeds(const DevCtx &cx, const LDS &L, int c, uint32_t n, uint32_t start) {
     uint32_t total = 0, k = 0;
     for (uint32_t i = 0; i < cx.I; i++) {
         uint32_t pos = s_prof[n & 15][i] + start - i;
-        pos = pos < (uint32_t)WaveLds<NWT>::MAXPOS ? pos : (uint32_t)WaveLds<NWT>::MAXPOS - 1;
+        pos = pos < (uint32_t)LDS::MAXPOS ? pos : (uint32_t)LDS::MAXPOS - 1;
         uint32_t s = L.seed[c][pos];
         if (s >> 31) k = 12;
         total += L.cnt[c][pos] << k;
@@ -309,8 +317,8 @@ __device__ __forceinline__ uint32_t count_seeds(const DevCtx &cx, const WaveLds<
 }
 
 // the global start offset (align.cpp:475-480); only meaningful when rc.ii > 0
-template <int NWT>
-__device__ uint32_t best_start_offset(const DevCtx &cx, const WaveLds<NWT> &L, const ReadCtx &rc, int c, int lane, uint32_t inherited) {
+template <class LDS>
+__device__ uint32_t best_start_offset(const DevCtx &cx, const LDS &L, const ReadCtx &rc, int c, int lane, uint32_t inherited) {
     uint32_t best = 0xffffffffu, so = inherited;
     for (uint32_t st = 0; st < rc.ii; st++) {
         uint32_t cs = (uint32_t)lane < rc.nseg ? count_seeds(cx, L, c, (uint32_t)lane, st) : 0;
@@ -321,8 +329,8 @@ __device__ uint32_t best_start_offset(const DevCtx &cx, const WaveLds<NWT> &L, c
 }
 
 // ---- step 3: ReorderSeed ------------------------------------------------------------------
-template <int NWT>
-__device__ void reorder_seed(const DevCtx &cx, WaveLds<NWT> &L, const ReadCtx &rc, int lane, uint32_t so0, uint32_t so1) {
+template <class LDS>
+__device__ void reorder_seed(const DevCtx &cx, LDS &L, const ReadCtx &rc, int lane, uint32_t so0, uint32_t so1) {
     uint32_t max_offset = rc.ii;
     for (int c = 0; c < 2; c++) {
         if (!rc.on(c)) continue;
@@ -434,6 +442,27 @@ __device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uin
         for (int w = 0; w < NWT; w++) c0 += popc64(D0[w] & prefix_pairs(lim - 32 * w));
         if (c0 >= thr - 1) return false;
     }
+    // Positions of the left-side mismatches with index thr-2, thr-3, thr-4 (the last one a gap of size 1, 2, 3 may use)
+    // and of the last mismatch at all: an upper bound G of every usable gap position. A right side that already
+    // holds thr-t mismatches behind the corresponding cut can never complete a hit, whatever i -- this rules out the
+    // random candidates (which pass the seed-side test whenever the seed sits near the read start) after one bitmap
+    // and a few popcounts per shift instead of the full (i, j) search. Pure pruning: the first (tt, i, j) found is unchanged.
+    int g_at[3] = {-1, -1, -1}, lastpos = -1;
+    uint32_t nleft = 0;
+#pragma unroll
+    for (int w = 0; w < NWT; w++) {
+        uint64_t bits = D0[w];
+        while (bits && nleft < thr - 1) {
+            int b = __clzll((long long)bits) >> 1;
+            bits &= ~(1ULL << (62 - 2 * b));
+            lastpos = w * 32 + b;
+            nleft++;
+            if (nleft == thr - 1) g_at[0] = lastpos;
+            if (nleft + 1 == thr - 1) g_at[1] = lastpos;
+            if (nleft + 2 == thr - 1) g_at[2] = lastpos;
+        }
+    }
+    if (nleft == 0) return false;  // no mismatch to put the gap at: every mmi1[i] is map_readlen
     for (uint32_t tt = 1; tt <= cx.gap * 2; tt++) {
         uint32_t t = (tt + 1) / 2;
         int shift = (tt & 1) ? -(int)t : (int)t;
@@ -442,6 +471,16 @@ __device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uin
         uint64_t D1[NWT];
         mismatch_map<NWT, NEWRULE>(xs, loc + (uint32_t)shift, q, rc.end_element, rc.end_offset, D1);
         int rl = len - (int)t - 1;
+        {
+            int G = nleft >= thr - t ? g_at[t - 1] : lastpos;  // >= every gap position the i-loop below can take
+            if (G > rl - 1) G = rl - 1;
+            int pcut_max = G - shift1;
+            if (pcut_max > len - (int)cx.gap_edge) pcut_max = len - (int)cx.gap_edge;
+            uint32_t J = 0;
+#pragma unroll
+            for (int v = 0; v < NWT; v++) J += popc64(D1[v] & ~prefix_pairs(pcut_max - 32 * v));
+            if (J >= thr - t) continue;
+        }
         uint32_t i = 0;  // index of the current left-side mismatch (mmi1[i])
 #pragma unroll
         for (int w = 0; w < NWT; w++) {
@@ -495,8 +534,8 @@ __device__ __forceinline__ uint64_t hit_key(uint32_t contig, uint32_t loc, bool 
 
 // int2hit + AddHit (align.cpp:319-346, align.h:329-347). All arguments wave-uniform.
 // returns 1 when SnpAlign must stop (level-0 cap), else 0; may lower st.thr.
-template <int NWT>
-__device__ uint32_t add_hit(const DevCtx &cx, WaveLds<NWT> &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t loc, uint32_t strand,
+template <class LDS>
+__device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t loc, uint32_t strand,
                             uint32_t chain, uint32_t w, uint32_t mode, int gap_size, uint32_t gap_pos, int lane) {
     // int2hit's binary search over ref_anchor (align.cpp:325-329), 64 probes per step: the largest
     // contig index whose anchor is <= loc (0 if none) -- one memory round trip for up to 64 contigs
@@ -579,7 +618,8 @@ __device__ uint32_t find_kth(const basal_hit *log, uint32_t nlog, uint32_t level
 
 // ---- one read ----------------------------------------------------------------------------------
 template <int NWT, bool NEWRULE, bool GAP>
-__device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *tab, basal_hit *log, uint32_t r, int lane) {
+__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8_t *tab, basal_hit *log, uint32_t r, int lane) {
+    using LDS = WaveLds<NWT, GAP>;
     basal_read rd = cx.reads[r];
     const bool allmodes = (rd.readset & BASAL_READ_ALLMODES) != 0;  // a PE mate: PairAlign::RunAlign drives the modes
     rd.readset &= 0x7f;
@@ -600,17 +640,17 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
         if (srcno < r) {
             basal_read src = cx.reads[srcno];
             rc.rno = r;
-            prep_read<NWT>(cx, L, tab, src, rc, lane);
-            if (rc.on(0)) so0 = best_start_offset<NWT>(cx, L, rc, 0, lane, so0);
-            if (rc.on(1)) so1 = best_start_offset<NWT>(cx, L, rc, 1, lane, so1);
+            prep_read(cx, L, tab, src, rc, lane);
+            if (rc.on(0)) so0 = best_start_offset(cx, L, rc, 0, lane, so0);
+            if (rc.on(1)) so1 = best_start_offset(cx, L, rc, 1, lane, so1);
         }
     }
     rc.rno = r;
-    prep_read<NWT>(cx, L, tab, rd, rc, lane);
+    prep_read(cx, L, tab, rd, rc, lane);
     if (stale) {  // seed slots past this read's own seeds still hold an earlier read's values
         if (lane < 30) {
             uint32_t c = (uint32_t)lane / 15, j = (uint32_t)lane % 15, pos = rc.npos + j;
-            if (rc.on(c) && pos < (uint32_t)WaveLds<NWT>::MAXPOS) {
+            if (rc.on(c) && pos < (uint32_t)LDS::MAXPOS) {
                 uint32_t sd = COLDP(const basal_stale, stales)[rd.stale_idx].overlay[c][j];
                 sd = (sd & 0x80000000u) | (uint32_t)guard_idx(cx, G_STALE, sd & 0x7fffffffu, COLD(total_kmers), r);
                 L.seed[c][pos] = sd;
@@ -620,13 +660,13 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
         }
         wave_sync();
     }
-    if (rc.on(0) && rc.ii > 0) so0 = best_start_offset<NWT>(cx, L, rc, 0, lane, so0);
-    if (rc.on(1) && rc.ii > 0) so1 = best_start_offset<NWT>(cx, L, rc, 1, lane, so1);
+    if (rc.on(0) && rc.ii > 0) so0 = best_start_offset(cx, L, rc, 0, lane, so0);
+    if (rc.on(1) && rc.ii > 0) so1 = best_start_offset(cx, L, rc, 1, lane, so1);
     res.start_off[0] = (uint8_t)so0;
     res.start_off[1] = (uint8_t)so1;
     if (lane < 32) L.nhit[lane >> 4][lane & 15] = 0;
     wave_sync();
-    reorder_seed<NWT>(cx, L, rc, lane, so0, so1);
+    reorder_seed(cx, L, rc, lane, so0, so1);
     HitState st;
     st.thr = rc.max_snp;
     st.nlog = 0;
@@ -644,7 +684,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
             if (rc.on(c)) {
                 uint32_t seg = L.order[c][mode];
                 uint32_t pos = s_prof[seg & 15][i] + L.start_arr[c][seg & 15] - i;
-                pos = (uint32_t)guard_idx(cx, G_LDSPOS, pos, WaveLds<NWT>::MAXPOS, r);
+                pos = (uint32_t)guard_idx(cx, G_LDSPOS, pos, LDS::MAXPOS, r);
                 uint32_t sd = L.seed[c][pos] & 0x7fffffffu, m = L.cnt[c][pos];
                 if (sd >= COLD(total_kmers)) sd = (uint32_t)guard_idx(cx, G_KMER2, 0x80000000u | pos | (seg << 16) | (c << 24) | (mode << 26), 0, r);
                 if (m != 0 && m <= cx.max_kmer_num) {
@@ -665,26 +705,71 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                 if (lane >= o) inc += v;
             }
         if ((uint32_t)lane < nent) {
-            // which flank of the seed has more read bases opposite it
+            // which flank of the seed has more read bases opposite it (GAP kernels test both flanks)
             int n_after = (int)rc.len - (int)(e_h + cx.K), n_before = (int)e_h;
             n_after = n_after < 0 ? 0 : n_after > 32 ? 32 : n_after;
             n_before = n_before > 32 ? 32 : n_before;
-            uint32_t side = n_before > n_after;
+            uint32_t side = GAP ? 0u : (uint32_t)(n_before > n_after);
             int p0 = side ? (int)e_h - 32 : (int)(e_h + cx.K);
             SeedEnt e = {e_off, e_m, e_nfwd, e_h, e_jj0, inc - e_m, e_chain, side,
                          plane_window<NWT>(L.q[e_chain][0], p0), plane_window<NWT>(L.q[e_chain][1], p0), plane_window<NWT>(L.q[e_chain][2], p0)};
             L.ent[lane] = e;
+            if (GAP) {
+                int pb = (int)e_h - 32;
+                SeedEntGap g = {plane_window<NWT>(L.q[e_chain][0], pb), plane_window<NWT>(L.q[e_chain][1], pb), plane_window<NWT>(L.q[e_chain][2], pb),
+                                n_before >= 32 ? kPairLo : (kPairLo & ((1ULL << (2 * n_before)) - 1))};  // the window's last n_before bases are read bases
+                L.entg[lane] = g;
+            }
         }
         wave_sync();
         const uint32_t T = rdlane(inc, (int)nent - 1);
 
-        for (uint32_t t0 = 0; t0 < T && !done; t0 += 64) {
-            uint32_t t = t0 + lane;
-            bool active = t < T;
+        // Non-GAP: 64 candidates of the stream per iteration. GAP: the flank tests run on the stream, the candidates they
+        // cannot rule out are compacted (order kept) into L.surv and scored + gap-searched 64 at a time, so the expensive
+        // part runs on full waves instead of on the ~quarter of the lanes that survive.
+        const uint64_t lt = (1ULL << lane) - 1;
+        uint32_t nsurv = 0, batch = 0;
+        for (uint32_t t0 = 0; (t0 < T || (GAP && nsurv > 0)) && !done;) {
+            uint32_t t;
+            bool active;
+            if (GAP) {
+                if (t0 < T && nsurv < 64) {
+                    uint32_t tf = t0 + lane;
+                    bool af = tf < T, keep = false;
+                    uint32_t eif = 0;
+                    for (uint32_t e = 0; e + 1 < nent; e++) eif += (tf >= rdlane(inc, (int)e));
+                    if (af) {
+                        const SeedEnt ef = L.ent[eif];
+                        const SeedEntGap g = L.entg[eif];
+                        uint32_t jj = ef.jj0 + (tf - ef.pre);
+                        if (jj >= ef.m) jj -= ef.m;
+                        const unsigned long long x = guard_idx(cx, G_LOCS, (unsigned long long)ef.off + jj, COLD(nlocs), r);
+                        uint64_t fa = cx.flank_a[x], fb = cx.flank_b[x];
+                        uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
+                        uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ef.fr, ef.fc, fa) & ef.fm) + XM64(db & g.bm);
+                        keep = lb <= st.thr || (st.thr >= 2 && XM64(db & g.bin) < st.thr - 1);
+                    }
+                    uint64_t mk = __ballot(keep);
+                    if (keep) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = tf;
+                    nsurv += (uint32_t)__popcll(mk);
+                    t0 += 64;
+                    wave_sync();
+                    if (t0 < T && nsurv < 64) continue;
+                }
+                batch = nsurv < 64 ? nsurv : 64;
+                if (batch == 0) continue;
+                active = (uint32_t)lane < batch;
+                t = active ? L.surv[lane] : 0;
+            } else {
+                t = t0 + lane;
+                active = t < T;
+                t0 += 64;
+            }
             uint32_t ei = 0;
             for (uint32_t e = 0; e + 1 < nent; e++) ei += (t >= rdlane(inc, (int)e));
             SeedEnt e = L.ent[active ? ei : 0];
             uint32_t loc = 0, strand = 0, mm = 0xffff;
+            bool gap_ok = false;  // GAP: the flank tests leave the gap search a chance
             const uint64_t(*q)[NWT + 1] = L.q[e.chain];
             if (active) {
                 uint32_t jj = e.jj0 + (t - e.pre);
@@ -698,6 +783,17 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                     uint64_t f = (e.side ? cx.flank_b : cx.flank_a)[ei_];
                     uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, f) & e.fm);
                     alive = lb <= st.thr;
+                } else {
+                    // both flanks: the ungapped count is at least the two windows' mismatches; the gap search gives up at
+                    // once when the read prefix up to the seed end already holds thr-1 mismatches (MismatchPattern0's
+                    // return value vs seed_pos+seed_size, align.cpp:365; no N mask there), and the window before the seed
+                    // is part of that prefix -- so a candidate that fails both tests needs no reference access at all
+                    const SeedEntGap g = L.entg[ei];
+                    uint64_t fa = cx.flank_a[ei_], fb = cx.flank_b[ei_];
+                    uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
+                    uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, fa) & e.fm) + XM64(db & g.bm);
+                    alive = lb <= st.thr;
+                    gap_ok = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
                 }
                 if (alive) {
                     uint32_t off2 = (loc & 31) * 2;
@@ -706,7 +802,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                 }
             }
             uint64_t act = __ballot(active);
-            uint64_t ung_pending = act, gap_pending = GAP ? act : 0;
+            uint64_t ung_pending = act, gap_pending = GAP ? (act & __ballot(gap_ok)) : 0;
             bool gfound = false;
             uint32_t gsnp = 0, gpos = 0;
             int gshift = 0;
@@ -729,7 +825,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                         acc &= ~bit;
                         ung_pending &= ~bit;
                         uint32_t lmm = rdlane(mm, l);
-                        if (add_hit<NWT>(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane)) { done = true; break; }
+                        if (add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane)) { done = true; break; }
                         if (st.thr != thr_before) {
                             acc = __ballot(active && mm <= st.thr) & acc;
                             if (GAP) { gap_pending &= ~(bit - 1); recompute = true; break; }
@@ -741,7 +837,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                         uint32_t lsnp = rdlane(gsnp, l), lgp = rdlane(gpos, l);
                         int lsh = (int)rdlane((uint32_t)gshift, l);
                         thr_before = st.thr;
-                        if (add_hit<NWT>(cx, L, st, log, rc, lloc, lstrand, lchain, lsnp, mode, lsh, lgp, lane)) { done = true; break; }
+                        if (add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lsnp, mode, lsh, lgp, lane)) { done = true; break; }
                         if (st.thr != thr_before) {
                             acc = __ballot(active && mm <= st.thr) & acc;
                             gap_pending &= ~((bit << 1) - 1);
@@ -751,6 +847,14 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT> &L, const uint8_t *t
                     }
                 }
                 if (!recompute || done) break;
+            }
+            if (GAP) {  // drop the processed batch from the front of the list
+                uint32_t rest = nsurv - batch;
+                uint32_t v = (uint32_t)lane < rest ? L.surv[batch + lane] : 0;
+                wave_sync();
+                if ((uint32_t)lane < rest) L.surv[lane] = v;
+                nsurv = rest;
+                wave_sync();
             }
         }
         // RunAlign: stop once any level <= mode holds a hit (align.cpp:462); `done` = AddHit said stop.
@@ -823,12 +927,12 @@ constexpr int waves_per_simd(int nwt, bool gap) { return nwt == 4 ? (gap ? 6 : 8
 template <int NWT, bool NEWRULE, bool GAP>
 __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(DevCtx cx) {
     __shared__ uint8_t s_tab[5 * 256];
-    __shared__ WaveLds<NWT> s_w[4];
+    __shared__ WaveLds<NWT, GAP> s_w[4];
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
     s_prof[threadIdx.x >> 4][threadIdx.x & 15] = (uint16_t)profile(threadIdx.x >> 4, threadIdx.x & 15, cx.K, cx.I);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    WaveLds<NWT> &L = s_w[wv];
+    WaveLds<NWT, GAP> &L = s_w[wv];
     if (lane <= NWT) {  // zero the pad words once
         for (int c = 0; c < 2; c++)
             for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
