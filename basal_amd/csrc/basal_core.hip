@@ -77,6 +77,20 @@ struct DevCtx {
 
 enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 5, G_KMER2 = 6, G_WATCHDOG = 7 };
 
+// Diagnostic build only (-DBASAL_PHASE_TIMING, `make prof`): per-phase shader-clock totals, summed over all waves
+// into d_counter[32..] and printed by basal_core_sync_check. The shipped library compiles these macros away.
+enum { PH_QUEUE = 0, PH_PACK, PH_SEEDS, PH_REORDER, PH_MODE, PH_FILTER, PH_SCORE, PH_REPLAY, PH_FINAL, PH_N };
+#ifdef BASAL_PHASE_TIMING
+struct PhaseClock { uint64_t last; uint64_t acc[PH_N]; };
+#define PH_PARAM , PhaseClock &phc
+#define PH_ARG , phc
+#define PH(k) do { uint64_t t_ = __builtin_readcyclecounter(); phc.acc[k] += t_ - phc.last; phc.last = t_; } while (0)
+#else
+#define PH_PARAM
+#define PH_ARG
+#define PH(k) do { } while (0)
+#endif
+
 // Cold kernel arguments are re-read from the kernarg segment where they are used (scalar loads through the
 // constant cache) instead of being kept live in SGPRs for the whole kernel, where they were spilled to VGPR
 // lanes (v_writelane/v_readlane are VALU work, and VALU issue is what bounds this kernel).
@@ -129,7 +143,10 @@ struct WaveLds {
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
     uint32_t seed[2][MAXPOS];   // XT hash; bit 31: seed window contains a non-ACGT base
     uint32_t cnt[2][MAXPOS];    // index2[seed].n[0]
-    SeedEnt ent[32];
+    union {
+        SeedEnt ent[32];      // the current mode's seeds
+        uint32_t cs[16][16];  // before the first mode: CountSeeds(n, start) of the chain being ordered
+    };
     SeedEntGap entg[GAP ? 32 : 1];
     uint32_t surv[GAP ? 128 : 1];  // GAP: stream indices of candidates the flank tests could not rule out, in visitation order
     uint16_t nhit[2][16];  // x_cur_n_hit[chain][level]
@@ -197,24 +214,23 @@ __device__ __forceinline__ uint32_t row16_min(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t row16_sum(uint32_t v) { return rdlane(row16_scan_add(v), 15); }
 
-// bit j of x -> bit 2j
-__device__ __forceinline__ uint64_t spread32(uint32_t x32) {
-    uint64_t x = x32;
-    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
-    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
-    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
-    x = (x | (x << 2)) & 0x3333333333333333ULL;
-    x = (x | (x << 1)) & 0x5555555555555555ULL;
-    return x;
+// every bit of a wave-uniform 32-bit value doubled (bit j -> bits 2j and 2j+1): one scalar instruction on gfx9
+__device__ __forceinline__ uint64_t bitreplicate(uint32_t x) {
+    uint64_t r;
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(r) : "s"(x));
+    return r;
 }
 
 // 64 lanes each hold one 2-bit code; returns the two packed words (lanes 0-31, lanes 32-63),
 // base of lane i at bits [63-2i, 62-2i] (MSB first, as ConvertBinaySeq packs, align.cpp:88-105)
 __device__ __forceinline__ void pack_codes(uint32_t code, uint64_t &w0, uint64_t &w1) {
     uint64_t b0 = __ballot(code & 1), b1 = __ballot(code & 2);
-    w0 = (spread32(__brev((uint32_t)b1)) << 1) | spread32(__brev((uint32_t)b0));
-    w1 = (spread32(__brev((uint32_t)(b1 >> 32))) << 1) | spread32(__brev((uint32_t)(b0 >> 32)));
+    w0 = (bitreplicate(__brev((uint32_t)b1)) & ~kPairLo) | (bitreplicate(__brev((uint32_t)b0)) & kPairLo);
+    w1 = (bitreplicate(__brev((uint32_t)(b1 >> 32))) & ~kPairLo) | (bitreplicate(__brev((uint32_t)(b0 >> 32))) & kPairLo);
 }
+
+// the word 32 lanes holding the same 2-bit code pack to
+__device__ __forceinline__ uint64_t code_fill(uint32_t code) { return ((code & 2) ? ~kPairLo : 0) | ((code & 1) ? kPairLo : 0); }
 
 struct ReadCtx {
     uint32_t len, index, readset, max_snp, seq_off;
@@ -228,7 +244,7 @@ struct ReadCtx {
 
 // ---- steps 1+2: pack, hash seeds, gather counts --------------------------------------------
 template <class LDS>
-__device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane) {
+__device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane PH_PARAM) {
     constexpr int NWT = LDS::NW;
     rc.len = rd.len;
     rc.index = rd.index;
@@ -251,16 +267,27 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
     for (int c = 0; c < 2; c++) {
         if (!rc.on(c)) continue;
         const uint8_t *al = tab + (c ? 256 : 0), *am = tab + (c ? 1024 : 768), *rg = tab + 512;
-        for (uint32_t b = 0; b <= (uint32_t)NWT / 2; b++) {
+        // all blocks' bytes are requested before the first is used (one memory round trip, not one per block)
+        uint32_t chs[NWT / 2];
+#pragma unroll
+        for (uint32_t b = 0; b < (uint32_t)NWT / 2; b++) {
             uint32_t pos = b * 64 + lane;
-            uint32_t ch = 0;
-            if (b < nblk && pos < rc.len) ch = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + (c ? rc.len - 1 - pos : pos), COLD(nbases), rc.rno)];
+            chs[b] = 0;
+            if (b < nblk && pos < rc.len) chs[b] = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + (c ? rc.len - 1 - pos : pos), COLD(nbases), rc.rno)];
+        }
+#pragma unroll
+        for (uint32_t b = 0; b <= (uint32_t)NWT / 2; b++) {
             uint64_t a0, a1, v0, v1, m0, m1;
-            uint32_t valid = rg[ch];
-            pack_codes(al[ch], a0, a1);
-            pack_codes(valid, v0, v1);
-            pack_codes(am[ch], m0, m1);
-            if (c == 0) ncnt += __popcll(__ballot(b < nblk && pos < rc.len && !valid));
+            if (b < nblk) {
+                const uint32_t ch = chs[b < (uint32_t)NWT / 2 ? b : 0], pos = b * 64 + lane;
+                uint32_t valid = rg[ch];
+                pack_codes(al[ch], a0, a1);
+                pack_codes(valid, v0, v1);
+                pack_codes(am[ch], m0, m1);
+                if (c == 0) ncnt += __popcll(__ballot(pos < rc.len && !valid));
+            } else {  // past the read: what 64 lanes holding byte 0 would pack to
+                a0 = a1 = code_fill(al[0]); v0 = v1 = code_fill(rg[0]); m0 = m1 = code_fill(am[0]);
+            }
             if (lane0(lane)) {
                 if (2 * b < (uint32_t)NWT + 1) { L.q[c][0][2 * b] = a0; L.q[c][1][2 * b] = v0; L.q[c][2][2 * b] = m0; }
                 if (2 * b + 1 < (uint32_t)NWT + 1) { L.q[c][0][2 * b + 1] = a1; L.q[c][1][2 * b + 1] = v1; L.q[c][2][2 * b + 1] = m1; }
@@ -276,6 +303,7 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
     }
     rc.n_count = cx.n_mis ? ncnt : 0;
     wave_sync();
+    PH(PH_PACK);
     // seeds: xseed_array / xseedreg_array (align.cpp:92-100) and their index counts
     const uint32_t kbits = 2 * cx.K;
     for (int c = 0; c < 2; c++) {
@@ -300,6 +328,7 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
         }
     }
     wave_sync();
+    PH(PH_SEEDS);
 }
 
 // CountSeeds (align.cpp:526-540)
@@ -328,39 +357,63 @@ __device__ uint32_t best_start_offset(const DevCtx &cx, const LDS &L, const Read
     return so;
 }
 
-// ---- step 3: ReorderSeed ------------------------------------------------------------------
+// ---- step 3: the start offset, AdjustSeedStartArray and ReorderSeed -------------------------------
+// CountSeeds(chain, n, start) is a pure function of (n, start) once the seeds are hashed, and the three
+// users (the global start offset, align.cpp:475-480; AdjustSeedStartArray, align.cpp:500-524; the
+// weights of ReorderSeed, align.cpp:492-495) only ever ask for start <= max(ii, inherited offset) < 16.
+// All needed values are computed in one lane-parallel sweep into L.cs (which shares storage with the
+// mode's seed entries, not live yet); the sequential walk over the segments then runs on table reads
+// with start_arr held in lane registers.
 template <class LDS>
-__device__ void reorder_seed(const DevCtx &cx, LDS &L, const ReadCtx &rc, int lane, uint32_t so0, uint32_t so1) {
-    uint32_t max_offset = rc.ii;
+__device__ void reorder_seed(const DevCtx &cx, LDS &L, const ReadCtx &rc, int lane, uint32_t &so0, uint32_t &so1) {
+    const uint32_t max_offset = rc.ii;
     for (int c = 0; c < 2; c++) {
         if (!rc.on(c)) continue;
-        if ((uint32_t)lane < 16) L.start_arr[c][lane] = (uint8_t)(c ? so1 : so0);
+        uint32_t so = c ? so1 : so0;
+        so = so < 16 ? so : 15;  // offsets are < K <= 16 by construction
+        const uint32_t smax = max_offset > so ? max_offset : so;
+        const uint32_t sh = smax ? 32u - (uint32_t)__builtin_clz(smax) : 0u;  // rows of 1 << sh lanes
+        for (uint32_t base = 0; base < rc.nseg; base += 64u >> sh) {
+            uint32_t n = base + ((uint32_t)lane >> sh), st = (uint32_t)lane & ((1u << sh) - 1);
+            if (n < rc.nseg && st <= smax) L.cs[n][st] = count_seeds(cx, L, c, n, st);
+        }
         wave_sync();
-        // AdjustSeedStartArray (align.cpp:500-524)
+        if (max_offset > 0) {  // the global start offset: the first st < ii with the smallest total
+            uint32_t tt = 0xffffffffu;
+            if ((uint32_t)lane < max_offset) {
+                tt = 0;
+                for (uint32_t n = 0; n < rc.nseg; n++) tt += L.cs[n][lane];
+            }
+            uint32_t m = row16_min(tt);
+            if (m != 0xffffffffu) so = (uint32_t)__ffsll((unsigned long long)__ballot((uint32_t)lane < max_offset && tt == m)) - 1;
+        }
+        if (c) so1 = so; else so0 = so;
+        // AdjustSeedStartArray: lane j holds start_arr[j]
+        uint32_t sa = so;
         for (uint32_t i = 0; i < rc.nseg; i++) {
             uint32_t ptr = (i % 2 == 0) ? i / 2 : rc.nseg - 1 - i / 2;
-            uint32_t start = (ptr == 0) ? 0 : L.start_arr[c][ptr - 1];
-            uint32_t end = (ptr == rc.nseg - 1) ? max_offset : L.start_arr[c][ptr + 1];
+            uint32_t start = (ptr == 0) ? 0 : rdlane(sa, (int)ptr - 1);
+            uint32_t end = (ptr == rc.nseg - 1) ? max_offset : rdlane(sa, (int)ptr + 1);
             uint32_t cand = start + lane;
             bool valid = cand <= end && lane < 16;
-            uint32_t tt = valid ? count_seeds(cx, L, c, ptr, cand) : 0xffffffffu;
+            uint32_t tt = valid ? L.cs[ptr][cand & 15] : 0xffffffffu;
             uint32_t m = row16_min(tt);  // valid lanes are < 16
             uint32_t pick = start;
             if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)__ballot(valid && tt == m)) - 1;
-            if (lane0(lane)) L.start_arr[c][ptr] = (uint8_t)pick;
-            wave_sync();
+            if ((uint32_t)lane == ptr) sa = pick;
         }
+        if (lane < 16) L.start_arr[c][lane] = (uint8_t)sa;
         // weights + sort ascending by (int weight, segment) (align.cpp:492-495)
         int32_t w = 0x7fffffff;
-        if ((uint32_t)lane < rc.nseg) w = (int32_t)count_seeds(cx, L, c, (uint32_t)lane, L.start_arr[c][lane]);
+        if ((uint32_t)lane < rc.nseg) w = (int32_t)L.cs[lane][sa & 15];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < rc.nseg; j++) {
             int32_t wj = (int32_t)rdlane((uint32_t)w, (int)j);
             rank += (wj < w) || (wj == w && j < (uint32_t)lane);
         }
         if ((uint32_t)lane < rc.nseg) L.order[c][rank] = (uint8_t)lane;
+        wave_sync();  // L.cs is rewritten for the other chain / by the seed entries
     }
-    wave_sync();
 }
 
 // ---- candidate scoring ----------------------------------------------------------------------
@@ -618,7 +671,7 @@ __device__ uint32_t find_kth(const basal_hit *log, uint32_t nlog, uint32_t level
 
 // ---- one read ----------------------------------------------------------------------------------
 template <int NWT, bool NEWRULE, bool GAP>
-__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8_t *tab, basal_hit *log, uint32_t r, int lane) {
+__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8_t *tab, basal_hit *log, uint32_t r, int lane PH_PARAM) {
     using LDS = WaveLds<NWT, GAP>;
     basal_read rd = cx.reads[r];
     const bool allmodes = (rd.readset & BASAL_READ_ALLMODES) != 0;  // a PE mate: PairAlign::RunAlign drives the modes
@@ -640,13 +693,13 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         if (srcno < r) {
             basal_read src = cx.reads[srcno];
             rc.rno = r;
-            prep_read(cx, L, tab, src, rc, lane);
+            prep_read(cx, L, tab, src, rc, lane PH_ARG);
             if (rc.on(0)) so0 = best_start_offset(cx, L, rc, 0, lane, so0);
             if (rc.on(1)) so1 = best_start_offset(cx, L, rc, 1, lane, so1);
         }
     }
     rc.rno = r;
-    prep_read(cx, L, tab, rd, rc, lane);
+    prep_read(cx, L, tab, rd, rc, lane PH_ARG);
     if (stale) {  // seed slots past this read's own seeds still hold an earlier read's values
         if (lane < 30) {
             uint32_t c = (uint32_t)lane / 15, j = (uint32_t)lane % 15, pos = rc.npos + j;
@@ -660,13 +713,12 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         }
         wave_sync();
     }
-    if (rc.on(0) && rc.ii > 0) so0 = best_start_offset(cx, L, rc, 0, lane, so0);
-    if (rc.on(1) && rc.ii > 0) so1 = best_start_offset(cx, L, rc, 1, lane, so1);
-    res.start_off[0] = (uint8_t)so0;
-    res.start_off[1] = (uint8_t)so1;
     if (lane < 32) L.nhit[lane >> 4][lane & 15] = 0;
     wave_sync();
     reorder_seed(cx, L, rc, lane, so0, so1);
+    res.start_off[0] = (uint8_t)so0;
+    res.start_off[1] = (uint8_t)so1;
+    PH(PH_REORDER);
     HitState st;
     st.thr = rc.max_snp;
     st.nlog = 0;
@@ -723,6 +775,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         }
         wave_sync();
         const uint32_t T = rdlane(inc, (int)nent - 1);
+        PH(PH_MODE);
 
         // Non-GAP: 64 candidates of the stream per iteration. GAP: the flank tests run on the stream, the candidates they
         // cannot rule out are compacted (order kept) into L.surv and scored + gap-searched 64 at a time, so the expensive
@@ -783,6 +836,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     uint64_t f = (e.side ? cx.flank_b : cx.flank_a)[ei_];
                     uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, f) & e.fm);
                     alive = lb <= st.thr;
+                    PH(PH_FILTER);
                 } else {
                     // both flanks: the ungapped count is at least the two windows' mismatches; the gap search gives up at
                     // once when the read prefix up to the seed end already holds thr-1 mismatches (MismatchPattern0's
@@ -794,6 +848,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, fa) & e.fm) + XM64(db & g.bm);
                     alive = lb <= st.thr;
                     gap_ok = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
+                    PH(PH_FILTER);
                 }
                 if (alive) {
                     uint32_t off2 = (loc & 31) * 2;
@@ -801,6 +856,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
                 }
             }
+            PH(PH_SCORE);
             uint64_t act = __ballot(active);
             uint64_t ung_pending = act, gap_pending = GAP ? (act & __ballot(gap_ok)) : 0;
             bool gfound = false;
@@ -848,6 +904,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 }
                 if (!recompute || done) break;
             }
+            PH(PH_REPLAY);
             if (GAP) {  // drop the processed batch from the front of the list
                 uint32_t rest = nsurv - batch;
                 uint32_t v = (uint32_t)lane < rest ? L.surv[batch + lane] : 0;
@@ -912,6 +969,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         res.stream_n = 0;
     }
     if (lane0(lane)) COLDP(basal_result, results)[r] = res;
+    PH(PH_FINAL);
 }
 
 // Resident waves per SIMD the register allocator is held to (= 256-thread blocks per CU). The kernel is
@@ -939,6 +997,11 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     }
     wave_sync();
     basal_hit *log = cx.scratch + (size_t)(blockIdx.x * 4 + wv) * COLD(scratch_per_wave);
+#ifdef BASAL_PHASE_TIMING
+    PhaseClock phc;
+    for (int i = 0; i < PH_N; i++) phc.acc[i] = 0;
+    phc.last = __builtin_readcyclecounter();
+#endif
     // Work queue: a wave takes WORK_CHUNK consecutive reads per atomic. One atomic per read would cap the
     // whole GPU at the rate a single memory word can be incremented (~88 M/s measured on MI355X; the
     // kernel ran at exactly that ceiling, independent of occupancy, before reads were taken in chunks).
@@ -950,14 +1013,19 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         uint32_t base = 0;
         if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)WORK_CHUNK);
         base = rfl(base);
+        PH(PH_QUEUE);
         if (base >= cx.n) break;
         if (iter > cx.n) { guard_idx(cx, G_WATCHDOG, iter, 0, base); break; }
         const uint32_t end = base + WORK_CHUNK < cx.n ? base + WORK_CHUNK : cx.n;
         for (uint32_t r = base; r < end; r++) {
             if (__ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x30000u | (uint32_t)__popcll(__ballot(1)), 0, r); break; }
-            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, lane);
+            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, lane PH_ARG);
         }
     }
+#ifdef BASAL_PHASE_TIMING
+    if (lane0(lane))
+        for (int i = 0; i < PH_N; i++) atomicAdd((unsigned long long *)(COLDP(unsigned int, guard) + 31) + i, (unsigned long long)phc.acc[i]);
+#endif
 }
 
 typedef void (*kernel_fn)(DevCtx);
@@ -1004,8 +1072,8 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
     memcpy(tabs + 768, p->alphabet_mread, 256);
     memcpy(tabs + 1024, p->rev_alphabet_mread, 256);
     HIP_TRY(hipMemcpy(c->d_tables, tabs, sizeof tabs, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&c->d_counter, 32 * sizeof(unsigned int)));
-    HIP_TRY(hipMemset(c->d_counter, 0, 32 * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&c->d_counter, 64 * sizeof(unsigned int)));  // [0] queue head, [1..24] guard ledger, [32..] phase clocks (diagnostic build)
+    HIP_TRY(hipMemset(c->d_counter, 0, 64 * sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&c->d_used, sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -1208,6 +1276,18 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
     HIP_TRY(hipMemcpyAsync(guard, c->d_counter + 1, sizeof guard, hipMemcpyDeviceToHost, c->last_stream));
     HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, sizeof guard, c->last_stream));
     HIP_TRY(hipStreamSynchronize(c->last_stream));
+#ifdef BASAL_PHASE_TIMING
+    {
+        static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final"};
+        unsigned long long ph[PH_N], tot = 0;
+        HIP_TRY(hipMemcpy(ph, c->d_counter + 32, sizeof ph, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(c->d_counter + 32, 0, sizeof ph));
+        for (int i = 0; i < PH_N; i++) tot += ph[i];
+        fprintf(stderr, "[basal phases]");
+        for (int i = 0; i < PH_N; i++) fprintf(stderr, " %s %.1f%%", nm[i], tot ? 100.0 * ph[i] / tot : 0.0);
+        fprintf(stderr, "  (total %llu wave-clocks)\n", tot);
+    }
+#endif
     return report_guard(guard);
 }
 

@@ -148,6 +148,8 @@ def main(argv=None):
     ap.add_argument("--frag-min", type=int, default=200)
     ap.add_argument("--frag-max", type=int, default=600)
     ap.add_argument("--fasta-reads", action="store_true", help="write reads as FASTA instead of FASTQ")
+    ap.add_argument("--lower-reads-frac", type=float, default=0.0, help="fraction of reads written in lower case")
+    ap.add_argument("--iupac-frac", type=float, default=0.0, help="fraction of reads given 1-3 IUPAC ambiguity codes (R, Y, K ...)")
     ap.add_argument("--pbat", action="store_true", help="emit the reverse complement of each SE read (PBAT, -n 2)")
     args = ap.parse_args(argv)
 
@@ -217,6 +219,12 @@ def main(argv=None):
             k = int(rng.integers(1, 8))
             m1 = m1.copy()
             m1[rng.choice(m1.size, size=k, replace=False)] = ord("N")
+        if rng.random() < args.iupac_frac:
+            m1 = m1.copy()
+            for q in rng.choice(m1.size, size=int(rng.integers(1, 4)), replace=False):
+                m1[q] = b"RYKMSW"[int(rng.integers(0, 6))]
+        if rng.random() < args.lower_reads_frac:
+            m1 = m1 | 0x20
         emit(f1, tag, revcomp(m1) if args.pbat else m1)
         if pe:
             m2 = revcomp(frag)[:rl]

@@ -88,6 +88,22 @@ FIXTURES = {
     "tx_ag_150": (["--ref-bp", "600000", "--contigs", "300", "--reads", "400", "-M", "A:G", "--p-conv", "0.9",
                    "--len", "150"],
                   ["-M", "A:G", "-S", "1", "-s", "12", "-n", "1"]),
+    # long reads: the 256-bp and 480-bp kernel instantiations, truncation at -L / the 480-bp cap
+    "long_300": (["--ref-bp", "300000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--len", "300", "--len-jitter", "120",
+                  "--max-sub", "12"],
+                 ["-M", "C:T", "-S", "1", "-s", "12", "-n", "1"]),
+    "long_490_g1": (["--ref-bp", "300000", "--contigs", "2", "--reads", "120", "-M", "A:G", "--p-conv", "0.8", "--len", "490",
+                     "--len-jitter", "60", "--max-sub", "10", "--indel-frac", "0.3", "--indel-max", "1"],
+                    ["-M", "A:G", "-S", "1", "-s", "12", "-g", "1", "-u"]),
+    "long_400_multi": (["--ref-bp", "300000", "--contigs", "2", "--reads", "100", "-M", "A:CGT", "--p-conv", "0.2", "--len", "400",
+                        "--max-sub", "8"],
+                       ["-M", "A:CGT", "-S", "1", "-s", "14", "-v", "0.04"]),
+    # edge cases: reads around the minimum length, lower-case and IUPAC read bases, hidden -N (N counts as a mismatch)
+    "edge_short": (["--ref-bp", "200000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--len", "40", "--len-jitter", "30",
+                    "--max-sub", "1", "--lower-reads-frac", "0.3", "--iupac-frac", "0.3"],
+                   ["-M", "C:T", "-S", "1", "-s", "12", "-u", "-f", "2"]),
+    "edge_Nmis": (["--ref-bp", "200000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--n-frac", "0.6", "--max-sub", "3"],
+                  ["-M", "C:T", "-S", "1", "-s", "12", "-u", "-N", "-n", "1"]),
     # FASTA reads input
     "fa_reads": (["--ref-bp", "200000", "--contigs", "2", "--reads", "200", "-M", "C:T", "--fasta-reads"],
                  ["-M", "C:T", "-S", "1", "-s", "12"]),
