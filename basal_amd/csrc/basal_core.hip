@@ -79,7 +79,7 @@ enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 
 
 // Diagnostic build only (-DBASAL_PHASE_TIMING, `make prof`): per-phase shader-clock totals, summed over all waves
 // into d_counter[32..] and printed by basal_core_sync_check. The shipped library compiles these macros away.
-enum { PH_QUEUE = 0, PH_PACK, PH_SEEDS, PH_REORDER, PH_MODE, PH_FILTER, PH_SCORE, PH_REPLAY, PH_FINAL, PH_N };
+enum { PH_QUEUE = 0, PH_PACK, PH_SEEDS, PH_REORDER, PH_MODE, PH_FILTER, PH_SCORE, PH_REPLAY, PH_FINAL, PH_CHUNK, PH_ENTRY, PH_BYTES, PH_E1, PH_E2, PH_E3, PH_N };
 #ifdef BASAL_PHASE_TIMING
 struct PhaseClock { uint64_t last; uint64_t acc[PH_N]; };
 #define PH_PARAM , PhaseClock &phc
@@ -105,7 +105,7 @@ __device__ __forceinline__ ColdCtxPtr cold_ctx() {
 #define COLDP(T, f) ((T *)(T __attribute__((address_space(1))) *)(cold_ctx()->f))
 
 __device__ __forceinline__ unsigned long long guard_idx(const DevCtx &cx, int kind, unsigned long long idx, unsigned long long lim, uint32_t r) {
-    if (idx < lim) return idx;
+    if (__builtin_expect(idx < lim, 1)) return idx;
     if (atomicAdd(&COLDP(unsigned int, guard)[kind], 1u) == 0) {
         COLDP(unsigned int, guard)[8 + kind] = (unsigned int)idx;
         COLDP(unsigned int, guard)[16 + kind] = r;
@@ -114,9 +114,12 @@ __device__ __forceinline__ unsigned long long guard_idx(const DevCtx &cx, int ki
 }
 
 struct SeedEnt {  // one (chain, phase) seed of the current mode
-    uint32_t off, m, nfwd, h, jj0, pre;  // pre = number of candidates before this seed in the mode's stream
-    uint32_t chain, side;                // side: 0 = test the flank after the seed, 1 = the flank before it
-    uint64_t fr, fm, fc;                 // the read's bases / valid mask / convert-to plane opposite that flank
+    uint32_t off, m, nfwd, jj0, pre;  // pre = number of candidates before this seed in the mode's stream
+    uint32_t hcs;                     // h | chain << 16 | side << 17; side: 0 = test the flank after the seed, 1 = the one before it
+    uint64_t fr, fm, fc;              // the read's bases / valid mask / convert-to plane opposite that flank
+    __device__ __forceinline__ uint32_t h() const { return hcs & 0xffffu; }
+    __device__ __forceinline__ uint32_t chain() const { return (hcs >> 16) & 1u; }
+    __device__ __forceinline__ uint32_t side() const { return hcs >> 17; }
 };
 
 // 32 read bases starting at read position p (may be negative or run past the read: those bases come
@@ -131,10 +134,16 @@ __device__ __forceinline__ uint64_t plane_window(const uint64_t *q, int p) {
 
 // Param::profile[j][i] (param.cpp:70-74), one copy per workgroup instead of an integer division per use
 __shared__ uint16_t s_prof[16][16];
+// the contig table of references with at most 64 contigs (int2hit then needs no memory access)
+__shared__ uint32_t s_anchor[64], s_rcoff[64], s_csize[64];
 
 struct SeedEntGap {  // GAP kernels: the read's window opposite the flank BEFORE the seed, and which of its bases lie in the read
     uint64_t br, bm, bc, bin;
 };
+
+#ifndef WORK_CHUNK
+#define WORK_CHUNK 8  // reads a wave takes from the queue per atomic
+#endif
 
 template <int NWT, bool GAP>
 struct WaveLds {
@@ -149,6 +158,8 @@ struct WaveLds {
     };
     SeedEntGap entg[GAP ? 32 : 1];
     uint32_t surv[GAP ? 128 : 1];  // GAP: stream indices of candidates the flank tests could not rule out, in visitation order
+    basal_read desc[WORK_CHUNK];   // the descriptors of the chunk of reads this wave took from the queue
+    basal_result res[WORK_CHUNK];  // and their results, written out together when the chunk is done
     uint16_t nhit[2][16];  // x_cur_n_hit[chain][level]
     uint8_t start_arr[2][16];
     uint8_t order[2][16];
@@ -242,9 +253,36 @@ struct ReadCtx {
     __device__ __forceinline__ bool on(int c) const { return (flags >> c) & 1u; }
 };
 
+// xflag_chain (align.cpp:83-84): bit c set = read chain c is aligned
+__device__ __forceinline__ uint32_t chain_flags(const DevCtx &cx, uint32_t rs) {
+    return (((cx.chains == 1) || ((cx.chains <= 1) == (rs < 2))) ? 1u : 0u) | (((cx.chains == 1) || ((cx.chains <= 1) == (rs == 2))) ? 2u : 0u);
+}
+
+// the read's bytes as chain c sees them (c = 1: back to front), lane l of block b <- read position 64 b + l
+template <int NWT>
+__device__ __forceinline__ void load_bases(const DevCtx &cx, const basal_read &rd, uint32_t rno, int c, int lane, uint32_t chs[NWT / 2]) {
+    const uint32_t len = rd.len <= (uint32_t)NWT * 32 ? rd.len : 0;  // over-long reads are skipped by process_read
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)NWT / 2; b++) {
+        uint32_t pos = b * 64 + lane;
+        chs[b] = 0;
+        if (pos < len) chs[b] = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rd.seq_off + (c ? len - 1 - pos : pos), COLD(nbases), rno)];
+    }
+}
+
+// a read descriptor as the wave-uniform value it is (scalar registers)
+__device__ __forceinline__ basal_read uniform_read(const basal_read &v) {
+    basal_read u;
+    u.seq_off = rfl(v.seq_off); u.index = rfl(v.index); u.stale_idx = rfl(v.stale_idx);
+    uint32_t w = rfl((uint32_t)v.len | ((uint32_t)v.readset << 16) | ((uint32_t)v.max_snp << 24));
+    u.len = (uint16_t)w; u.readset = (uint8_t)(w >> 16); u.max_snp = (uint8_t)(w >> 24);
+    return u;
+}
+
 // ---- steps 1+2: pack, hash seeds, gather counts --------------------------------------------
+// pre/pre_c: the bytes of chain pre_c fetched ahead by the caller (pre_c < 0: none)
 template <class LDS>
-__device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane PH_PARAM) {
+__device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane, const uint32_t *pre, int pre_c PH_PARAM) {
     constexpr int NWT = LDS::NW;
     rc.len = rd.len;
     rc.index = rd.index;
@@ -252,8 +290,7 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
     rc.readset = rs;
     rc.max_snp = rd.max_snp;
     rc.seq_off = rd.seq_off;
-    // xflag_chain (align.cpp:83-84)
-    rc.flags = (((cx.chains == 1) || ((cx.chains <= 1) == (rs < 2))) ? 1u : 0u) | (((cx.chains == 1) || ((cx.chains <= 1) == (rs == 2))) ? 2u : 0u);
+    rc.flags = chain_flags(cx, rs);
     {  // seedseg_num (align.cpp:450)
         int x = (int)((rc.len - cx.I + 1) / cx.K), y = (int)(rc.max_snp + 1);
         rc.nseg = (uint32_t)(x < y ? x : y);
@@ -269,12 +306,14 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
         const uint8_t *al = tab + (c ? 256 : 0), *am = tab + (c ? 1024 : 768), *rg = tab + 512;
         // all blocks' bytes are requested before the first is used (one memory round trip, not one per block)
         uint32_t chs[NWT / 2];
+        if (c == pre_c) {
 #pragma unroll
-        for (uint32_t b = 0; b < (uint32_t)NWT / 2; b++) {
-            uint32_t pos = b * 64 + lane;
-            chs[b] = 0;
-            if (b < nblk && pos < rc.len) chs[b] = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + (c ? rc.len - 1 - pos : pos), COLD(nbases), rc.rno)];
-        }
+            for (int b = 0; b < NWT / 2; b++) chs[b] = pre[b];
+        } else load_bases<NWT>(cx, rd, rc.rno, c, lane, chs);
+#ifdef BASAL_PHASE_TIMING
+        __builtin_amdgcn_s_waitcnt(0);
+        PH(PH_BYTES);
+#endif
 #pragma unroll
         for (uint32_t b = 0; b <= (uint32_t)NWT / 2; b++) {
             uint64_t a0, a1, v0, v1, m0, m1;
@@ -575,14 +614,36 @@ __device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uin
 }
 
 // ---- the sequential hit state of one read (wave-uniform) ----------------------------------
+// The hit log keeps every stored hit in insertion order. Its first 64 records live in registers, record i in
+// lane i (the common read stores one or a few hits: no memory round trip to store, de-duplicate or pick one);
+// records 64.. go to the wave's log in global memory.
 struct HitState {
     uint32_t thr;     // snp_thres
     uint32_t nlog;    // records in the log
-    uint64_t key0, key1;  // per lane: de-dup keys of log records lane and lane+64
+    uint32_t d0, d1, d2, d3;  // per lane: the four words of log record `lane`
 };
 
 __device__ __forceinline__ uint64_t hit_key(uint32_t contig, uint32_t loc, bool gapped) {
     return ((uint64_t)contig << 33) | ((uint64_t)gapped << 32) | loc;
+}
+
+union HitWords {
+    basal_hit h;
+    uint32_t w[4];
+};
+// log record i of the read (all lanes get it); i < nlog
+__device__ __forceinline__ basal_hit log_record(const HitState &st, const basal_hit *log, uint32_t i) {
+    HitWords u;
+    if (i < 64) { u.w[0] = rdlane(st.d0, (int)i); u.w[1] = rdlane(st.d1, (int)i); u.w[2] = rdlane(st.d2, (int)i); u.w[3] = rdlane(st.d3, (int)i); }
+    else u.h = log[i];
+    return u.h;
+}
+// this lane's record of the 64-record block starting at `base` (base + lane < nlog)
+__device__ __forceinline__ basal_hit log_lane_record(const HitState &st, const basal_hit *log, uint32_t base, int lane) {
+    HitWords u;
+    if (base == 0) { u.w[0] = st.d0; u.w[1] = st.d1; u.w[2] = st.d2; u.w[3] = st.d3; }
+    else u.h = log[base + lane];
+    return u.h;
 }
 
 // int2hit + AddHit (align.cpp:319-346, align.h:329-347). All arguments wave-uniform.
@@ -593,29 +654,37 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     // int2hit's binary search over ref_anchor (align.cpp:325-329), 64 probes per step: the largest
     // contig index whose anchor is <= loc (0 if none) -- one memory round trip for up to 64 contigs
     uint32_t left = 0, right = COLD(ncontig);
-    while (right - left > 1) {
-        uint32_t span = right - left, stride = (span + 63) / 64;
-        uint32_t idx = left + (uint32_t)lane * stride;
-        bool le = idx < right && COLDP(const uint32_t, ref_anchor)[idx] <= loc;
-        uint32_t k = (uint32_t)__popcll(__ballot(le));  // probes are ascending, so the true ones form a prefix
-        if (k == 0) { right = left + 1; break; }
-        left = left + (k - 1) * stride;
-        right = left + stride < right ? left + stride : right;
-    }
+    const bool cached = right <= 64;
+    if (cached) {
+        uint32_t k = (uint32_t)__popcll(__ballot((uint32_t)lane < right && s_anchor[lane] <= loc));
+        left = k ? k - 1 : 0;
+    } else
+        while (right - left > 1) {
+            uint32_t span = right - left, stride = (span + 63) / 64;
+            uint32_t idx = left + (uint32_t)lane * stride;
+            bool le = idx < right && COLDP(const uint32_t, ref_anchor)[idx] <= loc;
+            uint32_t k = (uint32_t)__popcll(__ballot(le));  // probes are ascending, so the true ones form a prefix
+            if (k == 0) { right = left + 1; break; }
+            left = left + (k - 1) * stride;
+            right = left + stride < right ? left + stride : right;
+        }
     uint32_t chr = (left * 2 + strand) & 0x3FFFF;
-    uint32_t l = loc - COLDP(const uint32_t, ref_anchor)[left];
+    uint32_t anchor, rcoff = 0, csize;  // separate branches: a select between an LDS and a global pointer would make flat loads
+    if (cached) { anchor = s_anchor[left]; csize = s_csize[left]; if (strand) rcoff = s_rcoff[left]; }
+    else { anchor = COLDP(const uint32_t, ref_anchor)[left]; csize = COLDP(const uint32_t, contig_size)[left]; if (strand) rcoff = COLDP(const uint32_t, rc_offset)[left]; }
+    uint32_t l = loc - anchor;
     uint32_t gp = gap_pos & 0x1FF;
     if (strand) {
-        l = COLDP(const uint32_t, rc_offset)[chr >> 1] - rc.len - l;
+        l = rcoff - rc.len - l;
         gp = (uint32_t)((int)rc.len + (gap_size < 0 ? gap_size : 0) - (int)gp) & 0x1FF;
         l -= (uint32_t)gap_size;
     }
     if ((int)l < 0) return 0;
-    if (l + rc.len > COLDP(const uint32_t, contig_size)[chr >> 1]) return 0;
+    if (l + rc.len > csize) return 0;
     uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
-    bool dup = ((uint32_t)lane < st.nlog && st.key0 == key) || ((uint32_t)lane + 64 < st.nlog && st.key1 == key);
+    bool dup = (uint32_t)lane < st.nlog && hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key;
     if (__ballot(dup)) return 0;
-    for (uint32_t base = 128; base < st.nlog; base += 64) {  // long logs: scan the spilled part
+    for (uint32_t base = 64; base < st.nlog; base += 64) {  // long logs: scan the part in memory
         bool d = false;
         if (base + lane < st.nlog) {
             basal_hit h = log[base + lane];
@@ -625,15 +694,15 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     }
     uint32_t n = st.nlog;
     if (n < COLD(scratch_per_wave)) {
-        if (lane0(lane)) {
-            basal_hit h;
-            h.loc = l; h.chr = chr; h.gap_size = (int8_t)gap_size; h.strand = (uint8_t)(((strand << 1) | chain) & 3);
-            h.gap_pos = (uint16_t)gp; h.level = (uint8_t)w; h.chain = (uint8_t)chain; h.mode = (uint8_t)mode; h.pad = 0;
-            log[n] = h;
+        HitWords u;
+        u.h.loc = l; u.h.chr = chr; u.h.gap_size = (int8_t)gap_size; u.h.strand = (uint8_t)(((strand << 1) | chain) & 3);
+        u.h.gap_pos = (uint16_t)gp; u.h.level = (uint8_t)w; u.h.chain = (uint8_t)chain; u.h.mode = (uint8_t)mode; u.h.pad = 0;
+        if (n < 64) {
+            if ((uint32_t)lane == n) { st.d0 = u.w[0]; st.d1 = u.w[1]; st.d2 = u.w[2]; st.d3 = u.w[3]; }
+        } else {
+            if (lane0(lane)) log[n] = u.h;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
-        if ((uint32_t)lane == n) st.key0 = key;
-        if ((uint32_t)lane + 64 == n) st.key1 = key;
         st.nlog = n + 1;
     }
     uint32_t tot;
@@ -651,11 +720,11 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
 }
 
 // k-th (0-based) log record with the given level and chain, in insertion order
-__device__ uint32_t find_kth(const basal_hit *log, uint32_t nlog, uint32_t level, uint32_t chain, uint32_t k, int lane) {
-    for (uint32_t base = 0; base < nlog; base += 64) {
+__device__ uint32_t find_kth(const HitState &st, const basal_hit *log, uint32_t level, uint32_t chain, uint32_t k, int lane) {
+    for (uint32_t base = 0; base < st.nlog; base += 64) {
         bool m = false;
-        if (base + lane < nlog) {
-            const basal_hit &h = log[base + lane];
+        if (base + lane < st.nlog) {
+            const basal_hit h = log_lane_record(st, log, base, lane);
             m = h.level == level && h.chain == chain;
         }
         uint64_t b = __ballot(m);
@@ -671,9 +740,9 @@ __device__ uint32_t find_kth(const basal_hit *log, uint32_t nlog, uint32_t level
 
 // ---- one read ----------------------------------------------------------------------------------
 template <int NWT, bool NEWRULE, bool GAP>
-__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8_t *tab, basal_hit *log, uint32_t r, int lane PH_PARAM) {
+__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
+                             const uint32_t *pre, int pre_c, int lane PH_PARAM) {
     using LDS = WaveLds<NWT, GAP>;
-    basal_read rd = cx.reads[r];
     const bool allmodes = (rd.readset & BASAL_READ_ALLMODES) != 0;  // a PE mate: PairAlign::RunAlign drives the modes
     rd.readset &= 0x7f;
     basal_result res;
@@ -681,25 +750,29 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
     res.best_level = 0xFF;
     if (rd.len == 0 || rd.len > (uint32_t)NWT * 32 || rd.len > BASAL_MAXREADLEN) {
         res.status = BASAL_READ_SKIPPED;
-        if (lane0(lane)) COLDP(basal_result, results)[r] = res;
+        if (lane0(lane)) L.res[chunk_slot] = res;
         return;
     }
     ReadCtx rc;
     uint32_t slot = rd.readset == 2 ? 1 : 0;
-    uint32_t so0 = COLD(carry)[slot][0], so1 = COLD(carry)[slot][1];
+    // the four carry bytes as one scalar load (a byte indexed by `slot` would be a vector load, and waiting for it
+    // would also wait for the bytes of the next read requested just before)
+    const uint32_t carry_w = *(const uint32_t __attribute__((address_space(4))) *)&cold_ctx()->carry[0][0] >> (16 * slot);
+    uint32_t so0 = carry_w & 0xff, so1 = (carry_w >> 8) & 0xff;
     const bool stale = rd.stale_idx < COLD(nstale);
     if (stale) {  // inherit xseed_start_offset from an earlier read of this batch (align.cpp:475-480)
         uint32_t srcno = COLDP(const basal_stale, stales)[rd.stale_idx].src;
         if (srcno < r) {
-            basal_read src = cx.reads[srcno];
+            basal_read src = uniform_read(cx.reads[srcno]);
             rc.rno = r;
-            prep_read(cx, L, tab, src, rc, lane PH_ARG);
+            prep_read(cx, L, tab, src, rc, lane, nullptr, -1 PH_ARG);
             if (rc.on(0)) so0 = best_start_offset(cx, L, rc, 0, lane, so0);
             if (rc.on(1)) so1 = best_start_offset(cx, L, rc, 1, lane, so1);
         }
     }
     rc.rno = r;
-    prep_read(cx, L, tab, rd, rc, lane PH_ARG);
+    PH(PH_ENTRY);
+    prep_read(cx, L, tab, rd, rc, lane, pre, pre_c PH_ARG);
     if (stale) {  // seed slots past this read's own seeds still hold an earlier read's values
         if (lane < 30) {
             uint32_t c = (uint32_t)lane / 15, j = (uint32_t)lane % 15, pos = rc.npos + j;
@@ -722,9 +795,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
     HitState st;
     st.thr = rc.max_snp;
     st.nlog = 0;
-    st.key0 = st.key1 = ~0ULL;
+    st.d0 = st.d1 = st.d2 = st.d3 = 0;
     const uint32_t rnd = myrand(rc.index, cx.randseed);
-    const uint32_t nent = 2 * cx.I;
+    const uint32_t nent = rfl(2 * cx.I);
     const uint32_t ent_c = (uint32_t)lane >= cx.I ? 1u : 0u, ent_i = (uint32_t)lane >= cx.I ? (uint32_t)lane - cx.I : (uint32_t)lane;  // lane < 2I
 
     bool done = false;
@@ -763,7 +836,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             n_before = n_before > 32 ? 32 : n_before;
             uint32_t side = GAP ? 0u : (uint32_t)(n_before > n_after);
             int p0 = side ? (int)e_h - 32 : (int)(e_h + cx.K);
-            SeedEnt e = {e_off, e_m, e_nfwd, e_h, e_jj0, inc - e_m, e_chain, side,
+            SeedEnt e = {e_off, e_m, e_nfwd, e_jj0, inc - e_m, e_h | (e_chain << 16) | (side << 17),
                          plane_window<NWT>(L.q[e_chain][0], p0), plane_window<NWT>(L.q[e_chain][1], p0), plane_window<NWT>(L.q[e_chain][2], p0)};
             L.ent[lane] = e;
             if (GAP) {
@@ -823,17 +896,22 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             SeedEnt e = L.ent[active ? ei : 0];
             uint32_t loc = 0, strand = 0, mm = 0xffff;
             bool gap_ok = false;  // GAP: the flank tests leave the gap search a chance
-            const uint64_t(*q)[NWT + 1] = L.q[e.chain];
+            const uint64_t(*q)[NWT + 1] = L.q[e.chain()];
             if (active) {
                 uint32_t jj = e.jj0 + (t - e.pre);
                 if (jj >= e.m) jj -= e.m;
                 const unsigned long long ei_ = guard_idx(cx, G_LOCS, (unsigned long long)e.off + jj, COLD(nlocs), r);
-                loc = cx.locs[ei_] - e.h;
+                // the location and the flank word(s) are requested together, before the location is looked at (its bounds
+                // check branches, and a load placed after the branch would cost a second memory round trip per chunk)
+                const uint32_t loc_raw = cx.locs[ei_];
+                uint64_t f = 0, fa = 0, fb = 0;
+                if (!GAP) f = (e.side() ? cx.flank_b : cx.flank_a)[ei_];
+                else { fa = cx.flank_a[ei_]; fb = cx.flank_b[ei_]; }
+                loc = loc_raw - e.h();
                 if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
                 strand = jj >= e.nfwd;
                 bool alive = true;
                 if (!GAP) {  // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
-                    uint64_t f = (e.side ? cx.flank_b : cx.flank_a)[ei_];
                     uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, f) & e.fm);
                     alive = lb <= st.thr;
                     PH(PH_FILTER);
@@ -843,7 +921,6 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     // return value vs seed_pos+seed_size, align.cpp:365; no N mask there), and the window before the seed
                     // is part of that prefix -- so a candidate that fails both tests needs no reference access at all
                     const SeedEntGap g = L.entg[ei];
-                    uint64_t fa = cx.flank_a[ei_], fb = cx.flank_b[ei_];
                     uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
                     uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, fa) & e.fm) + XM64(db & g.bm);
                     alive = lb <= st.thr;
@@ -867,7 +944,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 if (GAP) {
                     bool mine = (gap_pending >> lane) & 1;
                     gfound = false;
-                    if (mine) gfound = gap_align<NWT, NEWRULE>(cx, cx.xref[strand], loc, q, rc, st.thr, e.h, gsnp, gpos, gshift);
+                    if (mine) gfound = gap_align<NWT, NEWRULE>(cx, cx.xref[strand], loc, q, rc, st.thr, e.h(), gsnp, gpos, gshift);
                 }
                 uint64_t acc = __ballot(active && mm <= st.thr) & ung_pending;
                 uint64_t gm = GAP ? (__ballot(gfound) & gap_pending) : 0;
@@ -876,7 +953,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     int l = __ffsll((unsigned long long)(acc | gm)) - 1;
                     uint64_t bit = 1ULL << l;
                     uint32_t thr_before = st.thr;
-                    uint32_t lloc = rdlane(loc, l), lstrand = rdlane(strand, l), lchain = rdlane(e.chain, l);
+                    uint32_t lloc = rdlane(loc, l), lstrand = rdlane(strand, l), lchain = rdlane(e.chain(), l);
                     if (acc & bit) {
                         acc &= ~bit;
                         ung_pending &= ~bit;
@@ -936,8 +1013,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         res.n_hit = (uint16_t)nh;
         res.n_chit = (uint16_t)nc;
         uint32_t j = sum == 1 ? 0 : rnd % sum;
-        uint32_t idx = j < nh ? find_kth(log, st.nlog, ii, 0, j, lane) : find_kth(log, st.nlog, ii, 1, j - nh, lane);
-        if (idx != 0xffffffffu) res.best = log[idx];
+        uint32_t idx = j < nh ? find_kth(st, log, ii, 0, j, lane) : find_kth(st, log, ii, 1, j - nh, lane);
+        if (idx != 0xffffffffu) res.best = log_record(st, log, idx);
         if (COLD(stream_mode) == BASAL_STREAM_BEST || COLD(stream_mode) == BASAL_STREAM_ALL) {
             uint32_t need = COLD(stream_mode) == BASAL_STREAM_ALL ? st.nlog : sum;
             unsigned long long first = 0;
@@ -947,7 +1024,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             res.stream_n = need;
             if (first + need > COLD(stream_cap)) res.status = BASAL_READ_OVERFLOW;
             else if (COLD(stream_mode) == BASAL_STREAM_ALL) {
-                for (uint32_t i = lane; i < st.nlog; i += 64) COLDP(basal_hit, stream)[first + i] = log[i];
+                for (uint32_t base = 0; base < st.nlog; base += 64)
+                    if (base + lane < st.nlog) COLDP(basal_hit, stream)[first + base + lane] = log_lane_record(st, log, base, lane);
             } else {
                 uint32_t outp = 0;
                 for (uint32_t c = 0; c < 2; c++)
@@ -955,7 +1033,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         bool m = false;
                         basal_hit h;
                         if (base + lane < st.nlog) {
-                            h = log[base + lane];
+                            h = log_lane_record(st, log, base, lane);
                             m = h.level == ii && h.chain == c;
                         }
                         uint64_t b = __ballot(m);
@@ -968,15 +1046,12 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         // hits exist only above read_max_snp_num: cannot happen (levels are <= thr <= max_snp); kept for safety
         res.stream_n = 0;
     }
-    if (lane0(lane)) COLDP(basal_result, results)[r] = res;
+    if (lane0(lane)) L.res[chunk_slot] = res;
     PH(PH_FINAL);
 }
 
 // Resident waves per SIMD the register allocator is held to (= 256-thread blocks per CU). The kernel is
 // bound by dependent memory round trips per read, so throughput ~ resident waves / per-read latency.
-#ifndef WORK_CHUNK
-#define WORK_CHUNK 8
-#endif
 // Measured on the bench workload (NWT=4, no gap): 100 / 126 / 133 Mreads/s at 4 / 6 / 8 waves per SIMD -- the few
 // registers spilled to scratch at 64 VGPRs cost less than the extra waves bring. Longer reads keep more planes and
 // bitmaps in registers and get fewer waves.
@@ -988,6 +1063,11 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     __shared__ WaveLds<NWT, GAP> s_w[4];
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
     s_prof[threadIdx.x >> 4][threadIdx.x & 15] = (uint16_t)profile(threadIdx.x >> 4, threadIdx.x & 15, cx.K, cx.I);
+    if (threadIdx.x < 64 && threadIdx.x < cx.ncontig && cx.ncontig <= 64) {
+        s_anchor[threadIdx.x] = cx.ref_anchor[threadIdx.x];
+        s_rcoff[threadIdx.x] = cx.rc_offset[threadIdx.x];
+        s_csize[threadIdx.x] = cx.contig_size[threadIdx.x];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     WaveLds<NWT, GAP> &L = s_w[wv];
@@ -1017,10 +1097,39 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         if (base >= cx.n) break;
         if (iter > cx.n) { guard_idx(cx, G_WATCHDOG, iter, 0, base); break; }
         const uint32_t end = base + WORK_CHUNK < cx.n ? base + WORK_CHUNK : cx.n;
+        // The chunk's descriptors come in with one load, and each read's bytes are requested while the read before it
+        // is being aligned, so a read starts on data that is already in registers (2 memory round trips per chunk
+        // instead of 2 per read).
+        if ((uint32_t)lane < end - base) L.desc[lane] = cx.reads[base + lane];
+        wave_sync();
+        basal_read nrd = uniform_read(L.desc[0]);
+        uint32_t npre[NWT / 2];
+        int npc = (chain_flags(cx, nrd.readset & 0x7fu) & 1u) ? 0 : 1;
+        load_bases<NWT>(cx, nrd, base, npc, lane, npre);
+        PH(PH_CHUNK);
         for (uint32_t r = base; r < end; r++) {
             if (__ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x30000u | (uint32_t)__popcll(__ballot(1)), 0, r); break; }
-            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, lane PH_ARG);
+            const basal_read rd = nrd;
+            const int pc = npc;
+            uint32_t pre[NWT / 2];
+#pragma unroll
+            for (int b = 0; b < NWT / 2; b++) pre[b] = npre[b];
+            PH(PH_E1);
+            if (r + 1 < end) {
+                nrd = uniform_read(L.desc[r + 1 - base]);
+                npc = (chain_flags(cx, nrd.readset & 0x7fu) & 1u) ? 0 : 1;
+                PH(PH_E2);
+                load_bases<NWT>(cx, nrd, r + 1, npc, lane, npre);
+            }
+            PH(PH_E3);
+            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, r - base, rd, pre, pc, lane PH_ARG);
         }
+        // the chunk's results leave in one coalesced store (a store per read would have every read wait for the
+        // previous read's write acknowledgement at its first memory wait)
+        wave_sync();
+        static_assert(WORK_CHUNK * sizeof(basal_result) == 64 * sizeof(uint32_t), "one dword per lane");
+        if ((uint32_t)lane < (end - base) * (uint32_t)(sizeof(basal_result) / 4))
+            ((uint32_t *)(COLDP(basal_result, results) + base))[lane] = ((const uint32_t *)L.res)[lane];
     }
 #ifdef BASAL_PHASE_TIMING
     if (lane0(lane))
@@ -1278,7 +1387,7 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
     HIP_TRY(hipStreamSynchronize(c->last_stream));
 #ifdef BASAL_PHASE_TIMING
     {
-        static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final"};
+        static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final", "chunk", "entry", "bytes", "e1", "e2", "e3"};
         unsigned long long ph[PH_N], tot = 0;
         HIP_TRY(hipMemcpy(ph, c->d_counter + 32, sizeof ph, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(c->d_counter + 32, 0, sizeof ph));
