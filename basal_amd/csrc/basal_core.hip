@@ -113,6 +113,11 @@ __device__ __forceinline__ unsigned long long guard_idx(const DevCtx &cx, int ki
     return 0;
 }
 
+__device__ __forceinline__ uint32_t guard_u32(const DevCtx &cx, int kind, uint32_t idx, uint32_t lim, uint32_t r) {
+    if (__builtin_expect(idx < lim, 1)) return idx;
+    return (uint32_t)guard_idx(cx, kind, idx, lim, r);
+}
+
 struct SeedEnt {  // one (chain, phase) seed of the current mode
     uint32_t off, m, nfwd, jj0, pre;  // pre = number of candidates before this seed in the mode's stream
     uint32_t hcs;                     // h | chain << 16 | side << 17; side: 0 = test the flank after the seed, 1 = the one before it
@@ -136,6 +141,8 @@ __device__ __forceinline__ uint64_t plane_window(const uint64_t *q, int p) {
 __shared__ uint16_t s_prof[16][16];
 // the contig table of references with at most 64 contigs (int2hit then needs no memory access)
 __shared__ uint32_t s_anchor[64], s_rcoff[64], s_csize[64];
+// ceil(2^16 / d) for d = 1..16: x / d == (x * s_rcp[d]) >> 16 for x < 4096
+__shared__ uint32_t s_rcp[17];
 
 struct SeedEntGap {  // GAP kernels: the read's window opposite the flank BEFORE the seed, and which of its bases lie in the read
     uint64_t br, bm, bc, bin;
@@ -261,12 +268,15 @@ __device__ __forceinline__ uint32_t chain_flags(const DevCtx &cx, uint32_t rs) {
 // the read's bytes as chain c sees them (c = 1: back to front), lane l of block b <- read position 64 b + l
 template <int NWT>
 __device__ __forceinline__ void load_bases(const DevCtx &cx, const basal_read &rd, uint32_t rno, int c, int lane, uint32_t chs[NWT / 2]) {
-    const uint32_t len = rd.len <= (uint32_t)NWT * 32 ? rd.len : 0;  // over-long reads are skipped by process_read
+    uint32_t len = rd.len <= (uint32_t)NWT * 32 ? rd.len : 0;  // over-long reads are skipped by process_read
+    // one wave-uniform bounds check for the whole read instead of one per byte
+    if ((unsigned long long)rd.seq_off + len > COLD(nbases)) { guard_idx(cx, G_BASES, (unsigned long long)rd.seq_off + len, 0, rno); len = 0; }
+    const uint8_t *p = cx.bases + rd.seq_off;
 #pragma unroll
     for (uint32_t b = 0; b < (uint32_t)NWT / 2; b++) {
         uint32_t pos = b * 64 + lane;
         chs[b] = 0;
-        if (pos < len) chs[b] = cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rd.seq_off + (c ? len - 1 - pos : pos), COLD(nbases), rno)];
+        if (pos < len) chs[b] = p[c ? len - 1 - pos : pos];
     }
 }
 
@@ -281,8 +291,10 @@ __device__ __forceinline__ basal_read uniform_read(const basal_read &v) {
 
 // ---- steps 1+2: pack, hash seeds, gather counts --------------------------------------------
 // pre/pre_c: the bytes of chain pre_c fetched ahead by the caller (pre_c < 0: none)
+// so0/so1: the start offsets the read inherits (they bound the seed positions that can be asked for)
 template <class LDS>
-__device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane, const uint32_t *pre, int pre_c PH_PARAM) {
+__device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane, const uint32_t *pre, int pre_c,
+                          uint32_t so0, uint32_t so1 PH_PARAM) {
     constexpr int NWT = LDS::NW;
     rc.len = rd.len;
     rc.index = rd.index;
@@ -343,13 +355,32 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
     rc.n_count = cx.n_mis ? ncnt : 0;
     wave_sync();
     PH(PH_PACK);
-    // seeds: xseed_array / xseedreg_array (align.cpp:92-100) and their index counts
+    // seeds: xseed_array / xseedreg_array (align.cpp:92-100) and their index counts.
+    // Only the positions CountSeeds and SnpAlign can ask for are hashed and looked up: phase i of segment n with a
+    // start offset st <= smax = max(ii, inherited offset) sits at profile[n][i] - i + st. With k = 16, I = 4 and
+    // 100-base reads that is 30 distinct positions of 85, and each position not looked up is a random index access
+    // saved. Duplicates (several (i, st) giving one position) fall on the same address and write the same values.
     const uint32_t kbits = 2 * cx.K;
     for (int c = 0; c < 2; c++) {
         if (!rc.on(c)) continue;
-        for (uint32_t p = lane; p < (uint32_t)LDS::MAXPOS; p += 64) {
+        uint32_t so = c ? so1 : so0;
+        so = so < 16 ? so : 15;
+        const uint32_t R = (rc.ii > so ? rc.ii : so) + 1, combos = rc.nseg * cx.I * R;
+        const bool sparse = combos < rc.npos;
+        const uint32_t rcpI = s_rcp[cx.I], rcpR = s_rcp[R];
+        if (sparse && lane0(lane)) { L.seed[c][LDS::MAXPOS - 1] = 0x80000000u; L.cnt[c][LDS::MAXPOS - 1] = 0; }  // where CountSeeds' clip lands
+        const uint32_t total = sparse ? combos : (uint32_t)LDS::MAXPOS;
+        for (uint32_t base = 0; base < total; base += 64) {
+            uint32_t p = base + lane;
+            bool valid = p < total;
+            if (sparse) {  // p -> (n, st, i) -> position
+                uint32_t rest = (p * rcpI) >> 16, i = p - rest * cx.I;  // exact for p < 4096, divisor <= 16
+                uint32_t n = (rest * rcpR) >> 16, st = rest - n * R;
+                p = valid ? s_prof[n & 15][i & 15] + st - i : 0;
+                valid = valid && p < (uint32_t)LDS::MAXPOS;
+            }
             uint32_t sd = 0x80000000u, ct = 0;  // out-of-read positions: "contains N", count 0
-            if (p < rc.npos) {
+            if (valid && p < rc.npos) {
                 uint32_t w = p >> 5, sh = (p & 31) * 2;
                 uint64_t a = L.q[c][0][w], b = L.q[c][1][w];
                 if (sh) {
@@ -362,8 +393,10 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
                 ct = cx.kmer_off[sd + 1] - cx.kmer_off[sd];
                 if ((~sb) & full) sd |= 0x80000000u;
             }
-            L.seed[c][p] = sd;
-            L.cnt[c][p] = ct;
+            if (valid) {
+                L.seed[c][p] = sd;
+                L.cnt[c][p] = ct;
+            }
         }
     }
     wave_sync();
@@ -765,14 +798,14 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         if (srcno < r) {
             basal_read src = uniform_read(cx.reads[srcno]);
             rc.rno = r;
-            prep_read(cx, L, tab, src, rc, lane, nullptr, -1 PH_ARG);
+            prep_read(cx, L, tab, src, rc, lane, nullptr, -1, 0, 0 PH_ARG);
             if (rc.on(0)) so0 = best_start_offset(cx, L, rc, 0, lane, so0);
             if (rc.on(1)) so1 = best_start_offset(cx, L, rc, 1, lane, so1);
         }
     }
     rc.rno = r;
     PH(PH_ENTRY);
-    prep_read(cx, L, tab, rd, rc, lane, pre, pre_c PH_ARG);
+    prep_read(cx, L, tab, rd, rc, lane, pre, pre_c, so0, so1 PH_ARG);
     if (stale) {  // seed slots past this read's own seeds still hold an earlier read's values
         if (lane < 30) {
             uint32_t c = (uint32_t)lane / 15, j = (uint32_t)lane % 15, pos = rc.npos + j;
@@ -869,7 +902,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         const SeedEntGap g = L.entg[eif];
                         uint32_t jj = ef.jj0 + (tf - ef.pre);
                         if (jj >= ef.m) jj -= ef.m;
-                        const unsigned long long x = guard_idx(cx, G_LOCS, (unsigned long long)ef.off + jj, COLD(nlocs), r);
+                        const uint32_t x = guard_u32(cx, G_LOCS, ef.off + jj, COLD(nlocs), r);
                         uint64_t fa = cx.flank_a[x], fb = cx.flank_b[x];
                         uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
                         uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ef.fr, ef.fc, fa) & ef.fm) + XM64(db & g.bm);
@@ -891,8 +924,23 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 active = t < T;
                 t0 += 64;
             }
+            // which seed's list candidate t belongs to = the number of list ends (inc[e], e < nent-1) that are <= t.
+            // Non-GAP: the chunk is 64 consecutive t, so that is the count at t0 plus the ends inside the chunk (one
+            // or two, typically) -- cheaper than comparing every lane against every end.
             uint32_t ei = 0;
-            for (uint32_t e = 0; e + 1 < nent; e++) ei += (t >= rdlane(inc, (int)e));
+            if (GAP) {
+                for (uint32_t e = 0; e + 1 < nent; e++) ei += (t >= rdlane(inc, (int)e));
+            } else {
+                const uint32_t tb = t0 - 64;  // this chunk's first t (t0 has been advanced)
+                const bool is_end = (uint32_t)lane + 1 < nent;
+                ei = (uint32_t)__popcll(__ballot(is_end && inc <= tb));
+                uint64_t inside = __ballot(is_end && inc > tb && inc - tb < 64);
+                while (inside) {
+                    int en = __ffsll((unsigned long long)inside) - 1;
+                    inside &= inside - 1;
+                    ei += ((uint32_t)lane >= rdlane(inc, en) - tb);
+                }
+            }
             SeedEnt e = L.ent[active ? ei : 0];
             uint32_t loc = 0, strand = 0, mm = 0xffff;
             bool gap_ok = false;  // GAP: the flank tests leave the gap search a chance
@@ -900,7 +948,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             if (active) {
                 uint32_t jj = e.jj0 + (t - e.pre);
                 if (jj >= e.m) jj -= e.m;
-                const unsigned long long ei_ = guard_idx(cx, G_LOCS, (unsigned long long)e.off + jj, COLD(nlocs), r);
+                // kmer_off is 32-bit, so list positions are too
+                const uint32_t ei_ = guard_u32(cx, G_LOCS, e.off + jj, COLD(nlocs), r);
                 // the location and the flank word(s) are requested together, before the location is looked at (its bounds
                 // check branches, and a load placed after the branch would cost a second memory round trip per chunk)
                 const uint32_t loc_raw = cx.locs[ei_];
@@ -1055,7 +1104,10 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
 // Measured on the bench workload (NWT=4, no gap): 100 / 126 / 133 Mreads/s at 4 / 6 / 8 waves per SIMD -- the few
 // registers spilled to scratch at 64 VGPRs cost less than the extra waves bring. Longer reads keep more planes and
 // bitmaps in registers and get fewer waves.
-constexpr int waves_per_simd(int nwt, bool gap) { return nwt == 4 ? (gap ? 6 : 8) : nwt == 8 ? (gap ? 3 : 5) : (gap ? 2 : 3); }
+#ifndef BASAL_W4NG
+#define BASAL_W4NG 8
+#endif
+constexpr int waves_per_simd(int nwt, bool gap) { return nwt == 4 ? (gap ? 6 : BASAL_W4NG) : nwt == 8 ? (gap ? 3 : 5) : (gap ? 2 : 3); }
 
 template <int NWT, bool NEWRULE, bool GAP>
 __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(DevCtx cx) {
@@ -1063,6 +1115,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     __shared__ WaveLds<NWT, GAP> s_w[4];
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
     s_prof[threadIdx.x >> 4][threadIdx.x & 15] = (uint16_t)profile(threadIdx.x >> 4, threadIdx.x & 15, cx.K, cx.I);
+    if (threadIdx.x >= 1 && threadIdx.x <= 16) s_rcp[threadIdx.x] = (65536u + threadIdx.x - 1) / threadIdx.x;
     if (threadIdx.x < 64 && threadIdx.x < cx.ncontig && cx.ncontig <= 64) {
         s_anchor[threadIdx.x] = cx.ref_anchor[threadIdx.x];
         s_rcoff[threadIdx.x] = cx.rc_offset[threadIdx.x];
