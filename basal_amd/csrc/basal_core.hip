@@ -137,6 +137,23 @@ __device__ __forceinline__ uint64_t plane_window(const uint64_t *q, int p) {
     return sh ? (q[w] << sh) | (q[w + 1] >> (64 - sh)) : q[w];
 }
 
+// the same window of the three planes of one chain (bases, valid mask, convert-to), one control flow for all
+template <int NWT, bool NEED_C>
+__device__ __forceinline__ void plane_window3(const uint64_t (*q)[NWT + 1], int p, uint64_t &a, uint64_t &b, uint64_t &c) {
+    a = b = c = 0;
+    if (p <= -32 || p >= NWT * 32) return;
+    if (p < 0) {
+        const int s = 2 * (-p);
+        a = q[0][0] >> s; b = q[1][0] >> s;
+        if (NEED_C) c = q[2][0] >> s;
+        return;
+    }
+    const uint32_t w = (uint32_t)p >> 5, sh = ((uint32_t)p & 31) * 2;  // (x >> 1) >> (63 - sh) is x >> (64 - sh), and 0 for sh = 0
+    a = (q[0][w] << sh) | ((q[0][w + 1] >> 1) >> (63 - sh));
+    b = (q[1][w] << sh) | ((q[1][w + 1] >> 1) >> (63 - sh));
+    if (NEED_C) c = (q[2][w] << sh) | ((q[2][w + 1] >> 1) >> (63 - sh));
+}
+
 // Param::profile[j][i] (param.cpp:70-74), one copy per workgroup instead of an integer division per use
 __shared__ uint16_t s_prof[16][16];
 // the contig table of references with at most 64 contigs (int2hit then needs no memory access)
@@ -869,12 +886,15 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             n_before = n_before > 32 ? 32 : n_before;
             uint32_t side = GAP ? 0u : (uint32_t)(n_before > n_after);
             int p0 = side ? (int)e_h - 32 : (int)(e_h + cx.K);
-            SeedEnt e = {e_off, e_m, e_nfwd, e_jj0, inc - e_m, e_h | (e_chain << 16) | (side << 17),
-                         plane_window<NWT>(L.q[e_chain][0], p0), plane_window<NWT>(L.q[e_chain][1], p0), plane_window<NWT>(L.q[e_chain][2], p0)};
+            uint64_t wr, wm, wc;
+            plane_window3<NWT, NEWRULE>(L.q[e_chain], p0, wr, wm, wc);
+            SeedEnt e = {e_off, e_m, e_nfwd, e_jj0, inc - e_m, e_h | (e_chain << 16) | (side << 17), wr, wm, wc};
             L.ent[lane] = e;
             if (GAP) {
                 int pb = (int)e_h - 32;
-                SeedEntGap g = {plane_window<NWT>(L.q[e_chain][0], pb), plane_window<NWT>(L.q[e_chain][1], pb), plane_window<NWT>(L.q[e_chain][2], pb),
+                uint64_t br, bm, bc;
+                plane_window3<NWT, NEWRULE>(L.q[e_chain], pb, br, bm, bc);
+                SeedEntGap g = {br, bm, bc,
                                 n_before >= 32 ? kPairLo : (kPairLo & ((1ULL << (2 * n_before)) - 1))};  // the window's last n_before bases are read bases
                 L.entg[lane] = g;
             }
@@ -954,7 +974,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 // check branches, and a load placed after the branch would cost a second memory round trip per chunk)
                 const uint32_t loc_raw = cx.locs[ei_];
                 uint64_t f = 0, fa = 0, fb = 0;
-                if (!GAP) f = (e.side() ? cx.flank_b : cx.flank_a)[ei_];
+                if (!GAP) f = cx.flank_a[(unsigned long long)ei_ + (e.side() ? (unsigned long long)COLD(nlocs) + 64 : 0ULL)];  // flank_b = flank_a + nlocs + 64
                 else { fa = cx.flank_a[ei_]; fb = cx.flank_b[ei_]; }
                 loc = loc_raw - e.h();
                 if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
@@ -1250,7 +1270,7 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
-    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_flank_b); hipFree(c->d_tables); hipFree(c->d_scratch);
+    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

@@ -101,10 +101,11 @@ __global__ __launch_bounds__(256) void fill_flanks(const uint64_t *__restrict__ 
 }  // namespace
 
 int basal_build_flanks(basal_core *c) {
-    hipFree(c->d_flank_a); hipFree(c->d_flank_b);
+    // one allocation, the "before" words right behind the "after" words: the kernel picks one by adding nlocs + 64 to the index
+    hipFree(c->d_flank_a);
     c->d_flank_a = c->d_flank_b = nullptr;
-    HIP_TRYI(hipMalloc(&c->d_flank_a, (c->nlocs + 64) * 8));
-    HIP_TRYI(hipMalloc(&c->d_flank_b, (c->nlocs + 64) * 8));
+    HIP_TRYI(hipMalloc(&c->d_flank_a, 2 * (c->nlocs + 64) * 8));
+    c->d_flank_b = c->d_flank_a + (c->nlocs + 64);
     hipLaunchKernelGGL(fill_flanks, dim3((c->total_kmers + 255) / 256), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], c->d_koff, c->d_knfwd, c->d_locs,
                        c->total_kmers, c->p.seed_size, c->d_flank_a, c->d_flank_b);
     HIP_TRYI(hipGetLastError());
