@@ -803,6 +803,22 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         if (lane0(lane)) L.res[chunk_slot] = res;
         return;
     }
+#ifdef BASAL_PERTURB_VALU  // sensitivity experiment only: extra VALU work per read
+    {
+        uint32_t x = lane;
+#pragma unroll 1
+        for (int i = 0; i < BASAL_PERTURB_VALU / 4; i++) asm volatile("v_add_u32 %0, %0, 1\n v_xor_b32 %0, %0, 3\n v_add_u32 %0, %0, 5\n v_xor_b32 %0, %0, 7" : "+v"(x));
+        if (x == 0x12345) L.nhit[0][0] = 1;
+    }
+#endif
+#ifdef BASAL_PERTURB_MEM  // sensitivity experiment only: extra independent random sector reads per read
+    {
+        uint32_t h = (r * 64u + (uint32_t)lane) * 2654435761u;
+        uint32_t x = 0;
+        if (lane < BASAL_PERTURB_MEM) x = cx.locs[h % COLD(nlocs)];
+        if (x == 0xfffffff1u) L.nhit[0][0] = 1;
+    }
+#endif
     ReadCtx rc;
     uint32_t slot = rd.readset == 2 ? 1 : 0;
     // the four carry bytes as one scalar load (a byte indexed by `slot` would be a vector load, and waiting for it
