@@ -565,6 +565,33 @@ __device__ __forceinline__ void mismatch_map(const uint64_t *__restrict__ xs, ui
     }
 }
 
+// The same bitmap cut from reference words already in registers: W[0..NWT+1] are the words from the one holding
+// base `first` on, `rel` (< 64) is the alignment's first base relative to W[0]. GapAlign compares one candidate
+// at up to 7 start positions loc-3..loc+3; they all lie in the same NWT+2 words, which are loaded once.
+template <int NWT, bool NEWRULE>
+__device__ __forceinline__ void mismatch_map_regs(const uint64_t W[NWT + 2], uint32_t rel, const uint64_t (*q)[NWT + 1], uint32_t end_element,
+                                                  uint32_t end_offset, uint64_t D[NWT]) {
+    const bool up = rel >= 32;
+    const uint32_t off2 = (rel & 31) * 2;
+#pragma unroll
+    for (int i = 0; i < NWT; i++) {
+        uint64_t d = 0;
+        if ((uint32_t)i <= end_element) {
+            const uint64_t cur = up ? W[i + 1] : W[i], nxt = up ? W[i + 2] : W[i + 1];
+            uint64_t tmp = (cur << off2) | ((nxt >> (63 - off2)) >> 1);
+            if (!NEWRULE) tmp ^= q[0][i] & XC64(tmp);
+            else {
+                uint64_t M2 = XC64(tmp) | q[2][i];
+                uint64_t M3 = M2_judge(M2);
+                tmp ^= ((~M3) & M2) | (M3 & q[0][i]);
+            }
+            if ((uint32_t)i == end_element) tmp = (tmp >> end_offset) << end_offset;
+            d = pair_mask(tmp);
+        }
+        D[i] = d;
+    }
+}
+
 // GapAlign (align.cpp:348-410) for one candidate, bit-parallel: instead of the reference's
 // position arrays mm_index[][] it keeps the mismatch bitmaps and answers "i-th mismatch from the
 // left" / "first mismatch at distance >= X from the right" with popcounts. Same decisions.
@@ -572,8 +599,16 @@ template <int NWT, bool NEWRULE>
 __device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uint32_t loc, const uint64_t (*q)[NWT + 1], const ReadCtx &rc, uint32_t thr,
                           uint32_t seed_pos, uint32_t &gap_snp, uint32_t &gap_pos_out, int &shift_out) {
     if (thr < 2) return false;
+    // one round trip for the reference words of all 2g+1 start positions (loc >= 12320 by construction, loc/32 + NWT + 4 < nwords checked by the caller)
+    const uint32_t first = loc - cx.gap, rel0 = (first & 31) + cx.gap;
+    uint64_t W[NWT + 2];
+    {
+        const uint64_t *sp = xs + (first >> 5);
+#pragma unroll
+        for (int i = 0; i < NWT + 2; i++) W[i] = (uint32_t)i <= rc.end_element + 2 ? sp[i] : 0;
+    }
     uint64_t D0[NWT];
-    mismatch_map<NWT, NEWRULE>(xs, loc, q, rc.end_element, rc.end_offset, D0);
+    mismatch_map_regs<NWT, NEWRULE>(W, rel0, q, rc.end_element, rc.end_offset, D0);
     const int len = (int)rc.len;
     // MismatchPattern0 returns the position of mismatch #(thr-1) (or len); GapAlign gives up if
     // that lies before the end of the seed (align.cpp:365): >= thr-1 mismatches in [0, seed end)
@@ -611,8 +646,16 @@ __device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uin
         int shift1 = shift < 0 ? shift : 0;
         if (thr < 1 + t) break;
         uint64_t D1[NWT];
-        mismatch_map<NWT, NEWRULE>(xs, loc + (uint32_t)shift, q, rc.end_element, rc.end_offset, D1);
+        mismatch_map_regs<NWT, NEWRULE>(W, (uint32_t)((int)rel0 + shift), q, rc.end_element, rc.end_offset, D1);
         int rl = len - (int)t - 1;
+        {
+            // a position that mismatches at both start positions costs one mismatch whichever side of the gap it falls on
+            // (the t inserted read bases excepted): i + j >= popc(D0 & D1) - (insertion ? t : 0) for every (i, j)
+            uint32_t both = 0;
+#pragma unroll
+            for (int v = 0; v < NWT; v++) both += popc64(D0[v] & D1[v]);
+            if (both >= thr - t + (shift < 0 ? t : 0)) continue;
+        }
         {
             int G = nleft >= thr - t ? g_at[t - 1] : lastpos;  // >= every gap position the i-loop below can take
             if (G > rl - 1) G = rl - 1;
@@ -1143,7 +1186,10 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
 #ifndef BASAL_W4NG
 #define BASAL_W4NG 8
 #endif
-constexpr int waves_per_simd(int nwt, bool gap) { return nwt == 4 ? (gap ? 6 : BASAL_W4NG) : nwt == 8 ? (gap ? 3 : 5) : (gap ? 2 : 3); }
+#ifndef BASAL_W4G
+#define BASAL_W4G 4
+#endif
+constexpr int waves_per_simd(int nwt, bool gap) { return nwt == 4 ? (gap ? BASAL_W4G : BASAL_W4NG) : nwt == 8 ? (gap ? 3 : 5) : (gap ? 2 : 3); }
 
 template <int NWT, bool NEWRULE, bool GAP>
 __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(DevCtx cx) {

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--rule", default="C:T")
     ap.add_argument("--gap", type=int, default=0)
+    ap.add_argument("--read-len", type=int, default=100, help="read length (the headline workload is 100; 150/300 exercise the 256/480-base kernels)")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +100,7 @@ def main():
     # ---- reads resident in HBM -----------------------------------------------------------------
     n_steps = args.steps + args.warmup
     n_reads = args.batch * n_steps
-    read_len = 100
+    read_len = args.read_len
     frm, to = "ACGT".index(args.rule[0].upper()), "ACGT".index(args.rule[2].upper()) if args.rule[2] in "ACGTacgt" else None
     chunks = []
     per = 2_000_000
@@ -177,9 +178,9 @@ def main():
         "value": reads_timed / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": "config 2: %d M synthetic 100 bp SE reads per GPU (%d per step), -M %s -g %d -S 1, hg38-sized synthetic genome "
+        "config": {"workload": "config 2: %d M synthetic %d bp SE reads per GPU (%d per step), -M %s -g %d -S 1, hg38-sized synthetic genome "
                                "(%.2f Gbp, %d contigs, N gaps, planted repeats), reference + seed index resident in HBM, reads resident in HBM"
-                               % (args.batch * args.steps // 1_000_000, args.batch, args.rule, args.gap, total_bp / 1e9, len(sizes)),
+                               % (args.batch * args.steps // 1_000_000, args.read_len, args.batch, args.rule, args.gap, total_bp / 1e9, len(sizes)),
                    "reads_per_step_per_gpu": args.batch, "genome_bp": total_bp, "index_entries": None, "aligned_frac": aligned / max(1, len(timed)),
                    "unique_frac": unique / max(1, len(timed)), "gathered_aligned_reads": gathered_aligned, "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
                    "index_build_s": round(t_index, 2)},
