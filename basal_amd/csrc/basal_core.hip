@@ -569,27 +569,27 @@ __device__ __forceinline__ void mismatch_map(const uint64_t *__restrict__ xs, ui
 // base `first` on, `rel` (< 64) is the alignment's first base relative to W[0]. GapAlign compares one candidate
 // at up to 7 start positions loc-3..loc+3; they all lie in the same NWT+2 words, which are loaded once.
 template <int NWT, bool NEWRULE>
-__device__ __forceinline__ void mismatch_map_regs(const uint64_t W[NWT + 2], uint32_t rel, const uint64_t (*q)[NWT + 1], uint32_t end_element,
-                                                  uint32_t end_offset, uint64_t D[NWT]) {
+__device__ __forceinline__ uint64_t mismatch_word_regs(const uint64_t W[NWT + 2], uint32_t rel, const uint64_t (*q)[NWT + 1], uint32_t end_element,
+                                                       uint32_t end_offset, int i) {
+    if ((uint32_t)i > end_element) return 0;
     const bool up = rel >= 32;
     const uint32_t off2 = (rel & 31) * 2;
-#pragma unroll
-    for (int i = 0; i < NWT; i++) {
-        uint64_t d = 0;
-        if ((uint32_t)i <= end_element) {
-            const uint64_t cur = up ? W[i + 1] : W[i], nxt = up ? W[i + 2] : W[i + 1];
-            uint64_t tmp = (cur << off2) | ((nxt >> (63 - off2)) >> 1);
-            if (!NEWRULE) tmp ^= q[0][i] & XC64(tmp);
-            else {
-                uint64_t M2 = XC64(tmp) | q[2][i];
-                uint64_t M3 = M2_judge(M2);
-                tmp ^= ((~M3) & M2) | (M3 & q[0][i]);
-            }
-            if ((uint32_t)i == end_element) tmp = (tmp >> end_offset) << end_offset;
-            d = pair_mask(tmp);
-        }
-        D[i] = d;
+    const uint64_t cur = up ? W[i + 1] : W[i], nxt = up ? W[i + 2] : W[i + 1];
+    uint64_t tmp = (cur << off2) | ((nxt >> (63 - off2)) >> 1);
+    if (!NEWRULE) tmp ^= q[0][i] & XC64(tmp);
+    else {
+        uint64_t M2 = XC64(tmp) | q[2][i];
+        uint64_t M3 = M2_judge(M2);
+        tmp ^= ((~M3) & M2) | (M3 & q[0][i]);
     }
+    if ((uint32_t)i == end_element) tmp = (tmp >> end_offset) << end_offset;
+    return pair_mask(tmp);
+}
+template <int NWT, bool NEWRULE>
+__device__ __forceinline__ void mismatch_map_regs(const uint64_t W[NWT + 2], uint32_t rel, const uint64_t (*q)[NWT + 1], uint32_t end_element,
+                                                  uint32_t end_offset, uint64_t D[NWT]) {
+#pragma unroll
+    for (int i = 0; i < NWT; i++) D[i] = mismatch_word_regs<NWT, NEWRULE>(W, rel, q, end_element, end_offset, i);
 }
 
 // GapAlign (align.cpp:348-410) for one candidate, bit-parallel: instead of the reference's
@@ -619,43 +619,61 @@ __device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uin
         for (int w = 0; w < NWT; w++) c0 += popc64(D0[w] & prefix_pairs(lim - 32 * w));
         if (c0 >= thr - 1) return false;
     }
-    // Positions of the left-side mismatches with index thr-2, thr-3, thr-4 (the last one a gap of size 1, 2, 3 may use)
-    // and of the last mismatch at all: an upper bound G of every usable gap position. A right side that already
-    // holds thr-t mismatches behind the corresponding cut can never complete a hit, whatever i -- this rules out the
-    // random candidates (which pass the seed-side test whenever the seed sits near the read start) after one bitmap
-    // and a few popcounts per shift instead of the full (i, j) search. Pure pruning: the first (tt, i, j) found is unchanged.
+    // Per shift, first the cheapest test: a position that mismatches at both start positions costs one mismatch whichever
+    // side of the gap it falls on (the t inserted read bases excepted), so i + j >= popc(D0 & D1) - (insertion ? t : 0) for
+    // every (i, j). The shifted bitmap is built word by word and dropped as soon as that bound is reached: a random
+    // candidate (they pass the seed-side test whenever the seed sits near the read start) dies after one or two words.
+    // Then (lazily, once) the positions of the left-side mismatches with index thr-2, thr-3, thr-4 (the last one a gap of
+    // size 1, 2, 3 may use) and of the last mismatch at all: an upper bound G of every usable gap position. A right side
+    // that already holds thr-t mismatches behind the corresponding cut can never complete a hit, whatever i.
+    // Pure pruning: the first (tt, i, j) found is unchanged.
     int g_at[3] = {-1, -1, -1}, lastpos = -1;
     uint32_t nleft = 0;
+    bool walked = false;
+    {
+        uint32_t any = 0;
 #pragma unroll
-    for (int w = 0; w < NWT; w++) {
-        uint64_t bits = D0[w];
-        while (bits && nleft < thr - 1) {
-            int b = __clzll((long long)bits) >> 1;
-            bits &= ~(1ULL << (62 - 2 * b));
-            lastpos = w * 32 + b;
-            nleft++;
-            if (nleft == thr - 1) g_at[0] = lastpos;
-            if (nleft + 1 == thr - 1) g_at[1] = lastpos;
-            if (nleft + 2 == thr - 1) g_at[2] = lastpos;
-        }
+        for (int w = 0; w < NWT; w++) any |= (uint32_t)(D0[w] != 0);
+        if (!any) return false;  // no mismatch to put the gap at: every mmi1[i] is map_readlen
     }
-    if (nleft == 0) return false;  // no mismatch to put the gap at: every mmi1[i] is map_readlen
     for (uint32_t tt = 1; tt <= cx.gap * 2; tt++) {
         uint32_t t = (tt + 1) / 2;
         int shift = (tt & 1) ? -(int)t : (int)t;
         int shift1 = shift < 0 ? shift : 0;
         if (thr < 1 + t) break;
         uint64_t D1[NWT];
-        mismatch_map_regs<NWT, NEWRULE>(W, (uint32_t)((int)rel0 + shift), q, rc.end_element, rc.end_offset, D1);
-        int rl = len - (int)t - 1;
         {
-            // a position that mismatches at both start positions costs one mismatch whichever side of the gap it falls on
-            // (the t inserted read bases excepted): i + j >= popc(D0 & D1) - (insertion ? t : 0) for every (i, j)
+            const uint32_t bound = thr - t + (shift < 0 ? t : 0), rel = (uint32_t)((int)rel0 + shift);
             uint32_t both = 0;
+            bool dead = false;
 #pragma unroll
-            for (int v = 0; v < NWT; v++) both += popc64(D0[v] & D1[v]);
-            if (both >= thr - t + (shift < 0 ? t : 0)) continue;
+            for (int v = 0; v < NWT; v++) {
+                D1[v] = 0;
+                if (!dead) {
+                    D1[v] = mismatch_word_regs<NWT, NEWRULE>(W, rel, q, rc.end_element, rc.end_offset, v);
+                    both += popc64(D0[v] & D1[v]);
+                    dead = both >= bound;
+                }
+            }
+            if (dead) continue;
         }
+        if (!walked) {
+            walked = true;
+#pragma unroll
+            for (int w = 0; w < NWT; w++) {
+                uint64_t bits = D0[w];
+                while (bits && nleft < thr - 1) {
+                    int b = __clzll((long long)bits) >> 1;
+                    bits &= ~(1ULL << (62 - 2 * b));
+                    lastpos = w * 32 + b;
+                    nleft++;
+                    if (nleft == thr - 1) g_at[0] = lastpos;
+                    if (nleft + 1 == thr - 1) g_at[1] = lastpos;
+                    if (nleft + 2 == thr - 1) g_at[2] = lastpos;
+                }
+            }
+        }
+        int rl = len - (int)t - 1;
         {
             int G = nleft >= thr - t ? g_at[t - 1] : lastpos;  // >= every gap position the i-loop below can take
             if (G > rl - 1) G = rl - 1;
