@@ -207,6 +207,8 @@ __device__ __forceinline__ bool lane0(int lane) {
     return lane == 0;
 }
 
+// HIP's __ballot takes an int and compares it with 0 again (v_cndmask + v_cmp on top of the compare that made it)
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
@@ -259,7 +261,7 @@ __device__ __forceinline__ uint64_t bitreplicate(uint32_t x) {
 // 64 lanes each hold one 2-bit code; returns the two packed words (lanes 0-31, lanes 32-63),
 // base of lane i at bits [63-2i, 62-2i] (MSB first, as ConvertBinaySeq packs, align.cpp:88-105)
 __device__ __forceinline__ void pack_codes(uint32_t code, uint64_t &w0, uint64_t &w1) {
-    uint64_t b0 = __ballot(code & 1), b1 = __ballot(code & 2);
+    uint64_t b0 = ballot(code & 1), b1 = ballot(code & 2);
     w0 = (bitreplicate(__brev((uint32_t)b1)) & ~kPairLo) | (bitreplicate(__brev((uint32_t)b0)) & kPairLo);
     w1 = (bitreplicate(__brev((uint32_t)(b1 >> 32))) & ~kPairLo) | (bitreplicate(__brev((uint32_t)(b0 >> 32))) & kPairLo);
 }
@@ -352,7 +354,7 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
                 pack_codes(al[ch], a0, a1);
                 pack_codes(valid, v0, v1);
                 pack_codes(am[ch], m0, m1);
-                if (c == 0) ncnt += __popcll(__ballot(pos < rc.len && !valid));
+                if (c == 0) ncnt += __popcll(ballot(pos < rc.len && !valid));
             } else {  // past the read: what 64 lanes holding byte 0 would pack to
                 a0 = a1 = code_fill(al[0]); v0 = v1 = code_fill(rg[0]); m0 = m1 = code_fill(am[0]);
             }
@@ -366,7 +368,7 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
         for (uint32_t b = 0; b < nblk; b++) {
             uint32_t pos = b * 64 + lane;
             uint32_t ch = pos < rc.len ? cx.bases[guard_idx(cx, G_BASES, (unsigned long long)rc.seq_off + pos, COLD(nbases), rc.rno)] : 'A';
-            ncnt += __popcll(__ballot(!tab[512 + ch]));
+            ncnt += __popcll(ballot(!tab[512 + ch]));
         }
     }
     rc.n_count = cx.n_mis ? ncnt : 0;
@@ -474,7 +476,7 @@ __device__ void reorder_seed(const DevCtx &cx, LDS &L, const ReadCtx &rc, int la
                 for (uint32_t n = 0; n < rc.nseg; n++) tt += L.cs[n][lane];
             }
             uint32_t m = row16_min(tt);
-            if (m != 0xffffffffu) so = (uint32_t)__ffsll((unsigned long long)__ballot((uint32_t)lane < max_offset && tt == m)) - 1;
+            if (m != 0xffffffffu) so = (uint32_t)__ffsll((unsigned long long)ballot((uint32_t)lane < max_offset && tt == m)) - 1;
         }
         if (c) so1 = so; else so0 = so;
         // AdjustSeedStartArray: lane j holds start_arr[j]
@@ -488,7 +490,7 @@ __device__ void reorder_seed(const DevCtx &cx, LDS &L, const ReadCtx &rc, int la
             uint32_t tt = valid ? L.cs[ptr][cand & 15] : 0xffffffffu;
             uint32_t m = row16_min(tt);  // valid lanes are < 16
             uint32_t pick = start;
-            if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)__ballot(valid && tt == m)) - 1;
+            if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)ballot(valid && tt == m)) - 1;
             if ((uint32_t)lane == ptr) sa = pick;
         }
         if (lane < 16) L.start_arr[c][lane] = (uint8_t)sa;
@@ -767,14 +769,14 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     uint32_t left = 0, right = COLD(ncontig);
     const bool cached = right <= 64;
     if (cached) {
-        uint32_t k = (uint32_t)__popcll(__ballot((uint32_t)lane < right && s_anchor[lane] <= loc));
+        uint32_t k = (uint32_t)__popcll(ballot((uint32_t)lane < right && s_anchor[lane] <= loc));
         left = k ? k - 1 : 0;
     } else
         while (right - left > 1) {
             uint32_t span = right - left, stride = (span + 63) / 64;
             uint32_t idx = left + (uint32_t)lane * stride;
             bool le = idx < right && COLDP(const uint32_t, ref_anchor)[idx] <= loc;
-            uint32_t k = (uint32_t)__popcll(__ballot(le));  // probes are ascending, so the true ones form a prefix
+            uint32_t k = (uint32_t)__popcll(ballot(le));  // probes are ascending, so the true ones form a prefix
             if (k == 0) { right = left + 1; break; }
             left = left + (k - 1) * stride;
             right = left + stride < right ? left + stride : right;
@@ -794,14 +796,14 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     if (l + rc.len > csize) return 0;
     uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
     bool dup = (uint32_t)lane < st.nlog && hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key;
-    if (__ballot(dup)) return 0;
+    if (ballot(dup)) return 0;
     for (uint32_t base = 64; base < st.nlog; base += 64) {  // long logs: scan the part in memory
         bool d = false;
         if (base + lane < st.nlog) {
             basal_hit h = log[base + lane];
             d = hit_key(h.chr >> 1, h.loc, h.gap_size != 0) == key;
         }
-        if (__ballot(d)) return 0;
+        if (ballot(d)) return 0;
     }
     uint32_t n = st.nlog;
     if (n < COLD(scratch_per_wave)) {
@@ -820,7 +822,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     {
         uint32_t a = L.nhit[chain][w] + 1u;
         if (lane0(lane)) L.nhit[chain][w] = (uint16_t)a;
-        tot = a + L.nhit[chain ^ 1][w];
+        tot = rfl(a + L.nhit[chain ^ 1][w]);  // the same in every lane; says so to the compiler (st.thr and the caller's loop exits stay scalar)
     }
     wave_sync();
     if (tot >= COLD(max_num_hits)) {
@@ -838,7 +840,7 @@ __device__ uint32_t find_kth(const HitState &st, const basal_hit *log, uint32_t 
             const basal_hit h = log_lane_record(st, log, base, lane);
             m = h.level == level && h.chain == chain;
         }
-        uint64_t b = __ballot(m);
+        uint64_t b = ballot(m);
         uint32_t c = (uint32_t)__popcll(b);
         if (k < c) {
             for (uint32_t i = 0; i < k; i++) b &= b - 1;
@@ -869,6 +871,23 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         uint32_t x = lane;
 #pragma unroll 1
         for (int i = 0; i < BASAL_PERTURB_VALU / 4; i++) asm volatile("v_add_u32 %0, %0, 1\n v_xor_b32 %0, %0, 3\n v_add_u32 %0, %0, 5\n v_xor_b32 %0, %0, 7" : "+v"(x));
+        if (x == 0x12345) L.nhit[0][0] = 1;
+    }
+#endif
+#ifdef BASAL_PERTURB_SALU  // sensitivity experiment only: extra scalar ALU work per read
+    {
+        uint32_t x = r;
+#pragma unroll 1
+        for (int i = 0; i < BASAL_PERTURB_SALU / 4; i++)
+            asm volatile("s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 3\n s_add_u32 %0, %0, 5\n s_xor_b32 %0, %0, 7" : "+s"(x) : : "scc");
+        if (x == 0x12345) L.nhit[0][0] = 1;
+    }
+#endif
+#ifdef BASAL_PERTURB_LDS  // sensitivity experiment only: extra LDS reads per read
+    {
+        uint32_t x = 0;
+#pragma unroll 1
+        for (int i = 0; i < BASAL_PERTURB_LDS; i++) x += ((volatile uint32_t *)L.seed[0])[(lane + i) & 63];
         if (x == 0x12345) L.nhit[0][0] = 1;
     }
 #endif
@@ -984,6 +1003,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         // cannot rule out are compacted (order kept) into L.surv and scored + gap-searched 64 at a time, so the expensive
         // part runs on full waves instead of on the ~quarter of the lanes that survive.
         const uint64_t lt = (1ULL << lane) - 1;
+        const uint32_t nlocs_u = COLD(nlocs);
+        const unsigned long long flank_b_off = (unsigned long long)nlocs_u + 64;  // flank_b = flank_a + nlocs + 64
         uint32_t nsurv = 0, batch = 0;
         for (uint32_t t0 = 0; (t0 < T || (GAP && nsurv > 0)) && !done;) {
             uint32_t t;
@@ -1005,7 +1026,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ef.fr, ef.fc, fa) & ef.fm) + XM64(db & g.bm);
                         keep = lb <= st.thr || (st.thr >= 2 && XM64(db & g.bin) < st.thr - 1);
                     }
-                    uint64_t mk = __ballot(keep);
+                    uint64_t mk = ballot(keep);
                     if (keep) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = tf;
                     nsurv += (uint32_t)__popcll(mk);
                     t0 += 64;
@@ -1030,8 +1051,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             } else {
                 const uint32_t tb = t0 - 64;  // this chunk's first t (t0 has been advanced)
                 const bool is_end = (uint32_t)lane + 1 < nent;
-                ei = (uint32_t)__popcll(__ballot(is_end && inc <= tb));
-                uint64_t inside = __ballot(is_end && inc > tb && inc - tb < 64);
+                ei = (uint32_t)__popcll(ballot(is_end && inc <= tb));
+                uint64_t inside = ballot(is_end && inc > tb && inc - tb < 64);
                 while (inside) {
                     int en = __ffsll((unsigned long long)inside) - 1;
                     inside &= inside - 1;
@@ -1046,12 +1067,12 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 uint32_t jj = e.jj0 + (t - e.pre);
                 if (jj >= e.m) jj -= e.m;
                 // kmer_off is 32-bit, so list positions are too
-                const uint32_t ei_ = guard_u32(cx, G_LOCS, e.off + jj, COLD(nlocs), r);
+                const uint32_t ei_ = guard_u32(cx, G_LOCS, e.off + jj, nlocs_u, r);
                 // the location and the flank word(s) are requested together, before the location is looked at (its bounds
                 // check branches, and a load placed after the branch would cost a second memory round trip per chunk)
                 const uint32_t loc_raw = cx.locs[ei_];
                 uint64_t f = 0, fa = 0, fb = 0;
-                if (!GAP) f = cx.flank_a[(unsigned long long)ei_ + (e.side() ? (unsigned long long)COLD(nlocs) + 64 : 0ULL)];  // flank_b = flank_a + nlocs + 64
+                if (!GAP) f = cx.flank_a[(unsigned long long)ei_ + (e.side() ? flank_b_off : 0ULL)];
                 else { fa = cx.flank_a[ei_]; fb = cx.flank_b[ei_]; }
                 loc = loc_raw - e.h();
                 if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
@@ -1080,8 +1101,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 }
             }
             PH(PH_SCORE);
-            uint64_t act = __ballot(active);
-            uint64_t ung_pending = act, gap_pending = GAP ? (act & __ballot(gap_ok)) : 0;
+            uint64_t act = ballot(active);
+            uint64_t ung_pending = act, gap_pending = GAP ? (act & ballot(gap_ok)) : 0;
             bool gfound = false;
             uint32_t gsnp = 0, gpos = 0;
             int gshift = 0;
@@ -1092,8 +1113,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     gfound = false;
                     if (mine) gfound = gap_align<NWT, NEWRULE>(cx, cx.xref[strand], loc, q, rc, st.thr, e.h(), gsnp, gpos, gshift);
                 }
-                uint64_t acc = __ballot(active && mm <= st.thr) & ung_pending;
-                uint64_t gm = GAP ? (__ballot(gfound) & gap_pending) : 0;
+                uint64_t acc = ballot(active && mm <= st.thr) & ung_pending;
+                uint64_t gm = GAP ? (ballot(gfound) & gap_pending) : 0;
                 bool recompute = false;
                 while (acc | gm) {
                     int l = __ffsll((unsigned long long)(acc | gm)) - 1;
@@ -1106,7 +1127,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         uint32_t lmm = rdlane(mm, l);
                         if (add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane)) { done = true; break; }
                         if (st.thr != thr_before) {
-                            acc = __ballot(active && mm <= st.thr) & acc;
+                            acc = ballot(active && mm <= st.thr) & acc;
                             if (GAP) { gap_pending &= ~(bit - 1); recompute = true; break; }
                         }
                     }
@@ -1118,7 +1139,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         thr_before = st.thr;
                         if (add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lsnp, mode, lsh, lgp, lane)) { done = true; break; }
                         if (st.thr != thr_before) {
-                            acc = __ballot(active && mm <= st.thr) & acc;
+                            acc = ballot(active && mm <= st.thr) & acc;
                             gap_pending &= ~((bit << 1) - 1);
                             recompute = true;
                             break;
@@ -1143,7 +1164,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         else {
             uint32_t any = 0;
             if ((uint32_t)lane <= mode && lane < 16) any = L.nhit[0][lane] | L.nhit[1][lane];
-            if (__ballot(any != 0)) done = true;
+            if (ballot(any != 0)) done = true;
         }
     }
 
@@ -1151,7 +1172,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint32_t tot = 0;
     if (lane < 16 && (uint32_t)lane <= rc.max_snp) tot = (uint32_t)L.nhit[0][lane] + L.nhit[1][lane];
-    uint64_t nz = __ballot(tot != 0);
+    uint64_t nz = ballot(tot != 0);
     if (nz) {
         uint32_t ii = (uint32_t)__ffsll((unsigned long long)nz) - 1;
         uint32_t nh = L.nhit[0][ii], nc = L.nhit[1][ii], sum = nh + nc;
@@ -1182,7 +1203,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                             h = log_lane_record(st, log, base, lane);
                             m = h.level == ii && h.chain == c;
                         }
-                        uint64_t b = __ballot(m);
+                        uint64_t b = ballot(m);
                         if (m) COLDP(basal_hit, stream)[first + outp + (uint32_t)__popcll(b & ((1ULL << lane) - 1))] = h;
                         outp += (uint32_t)__popcll(b);
                     }
@@ -1242,7 +1263,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     // against an internal error (a wave cannot legitimately take more than n reads).
     for (uint32_t iter = 0;; iter++) {
         // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
-        if (__ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(__ballot(1)), 0, iter); break; }
+        if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(ballot(1)), 0, iter); break; }
         uint32_t base = 0;
         if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)WORK_CHUNK);
         base = rfl(base);
@@ -1261,7 +1282,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         load_bases<NWT>(cx, nrd, base, npc, lane, npre);
         PH(PH_CHUNK);
         for (uint32_t r = base; r < end; r++) {
-            if (__ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x30000u | (uint32_t)__popcll(__ballot(1)), 0, r); break; }
+            if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x30000u | (uint32_t)__popcll(ballot(1)), 0, r); break; }
             const basal_read rd = nrd;
             const int pc = npc;
             uint32_t pre[NWT / 2];
