@@ -169,6 +169,11 @@ struct SeedEntGap {  // GAP kernels: the read's window opposite the flank BEFORE
 #define WORK_CHUNK 8  // reads a wave takes from the queue per atomic
 #endif
 
+struct SurvEnt {  // a gap-eligible or still-alive candidate of the stream
+    uint32_t loc;   // alignment start (bounds-checked)
+    uint32_t meta;  // seed entry | strand << 8 | passed the ungapped flank bound << 9 | passed the gap-side bound << 10
+};
+
 template <int NWT, bool GAP>
 struct WaveLds {
     static constexpr int NW = NWT;
@@ -181,7 +186,7 @@ struct WaveLds {
         uint32_t cs[16][16];  // before the first mode: CountSeeds(n, start) of the chain being ordered
     };
     SeedEntGap entg[GAP ? 32 : 1];
-    uint32_t surv[GAP ? 128 : 1];  // GAP: stream indices of candidates the flank tests could not rule out, in visitation order
+    SurvEnt surv[GAP ? 128 : 1];  // GAP: the candidates the flank tests could not rule out, in visitation order
     basal_read desc[WORK_CHUNK];   // the descriptors of the chunk of reads this wave took from the queue
     basal_result res[WORK_CHUNK];  // and their results, written out together when the chunk is done
     uint16_t nhit[2][16];  // x_cur_n_hit[chain][level]
@@ -598,19 +603,10 @@ __device__ __forceinline__ void mismatch_map_regs(const uint64_t W[NWT + 2], uin
 // position arrays mm_index[][] it keeps the mismatch bitmaps and answers "i-th mismatch from the
 // left" / "first mismatch at distance >= X from the right" with popcounts. Same decisions.
 template <int NWT, bool NEWRULE>
-__device__ bool gap_align(const DevCtx &cx, const uint64_t *__restrict__ xs, uint32_t loc, const uint64_t (*q)[NWT + 1], const ReadCtx &rc, uint32_t thr,
-                          uint32_t seed_pos, uint32_t &gap_snp, uint32_t &gap_pos_out, int &shift_out) {
+// W = the reference words from the one holding base loc-g on, rel0 = loc relative to W[0], D0 = the ungapped bitmap.
+__device__ bool gap_align(const DevCtx &cx, const uint64_t W[NWT + 2], uint32_t rel0, const uint64_t D0[NWT], const uint64_t (*q)[NWT + 1], const ReadCtx &rc,
+                          uint32_t thr, uint32_t seed_pos, uint32_t &gap_snp, uint32_t &gap_pos_out, int &shift_out) {
     if (thr < 2) return false;
-    // one round trip for the reference words of all 2g+1 start positions (loc >= 12320 by construction, loc/32 + NWT + 4 < nwords checked by the caller)
-    const uint32_t first = loc - cx.gap, rel0 = (first & 31) + cx.gap;
-    uint64_t W[NWT + 2];
-    {
-        const uint64_t *sp = xs + (first >> 5);
-#pragma unroll
-        for (int i = 0; i < NWT + 2; i++) W[i] = (uint32_t)i <= rc.end_element + 2 ? sp[i] : 0;
-    }
-    uint64_t D0[NWT];
-    mismatch_map_regs<NWT, NEWRULE>(W, rel0, q, rc.end_element, rc.end_offset, D0);
     const int len = (int)rc.len;
     // MismatchPattern0 returns the position of mismatch #(thr-1) (or len); GapAlign gives up if
     // that lies before the end of the seed (align.cpp:365): >= thr-1 mismatches in [0, seed end)
@@ -1011,23 +1007,38 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             bool active;
             if (GAP) {
                 if (t0 < T && nsurv < 64) {
-                    uint32_t tf = t0 + lane;
-                    bool af = tf < T, keep = false;
-                    uint32_t eif = 0;
-                    for (uint32_t e = 0; e + 1 < nent; e++) eif += (tf >= rdlane(inc, (int)e));
+                    const uint32_t tf = t0 + lane;
+                    const bool af = tf < T, is_end = (uint32_t)lane + 1 < nent;
+                    bool keep = false;
+                    uint32_t eif = (uint32_t)__popcll(ballot(is_end && inc <= t0));  // the list tf belongs to (as below)
+                    for (uint64_t inside = ballot(is_end && inc > t0 && inc - t0 < 64); inside; inside &= inside - 1)
+                        eif += ((uint32_t)lane >= rdlane(inc, __ffsll((unsigned long long)inside) - 1) - t0);
+                    SurvEnt sv = {0, 0};
                     if (af) {
+                        // both flanks: the ungapped count is at least the two windows' mismatches; the gap search gives up at
+                        // once when the read prefix up to the seed end already holds thr-1 mismatches (MismatchPattern0's
+                        // return value vs seed_pos+seed_size, align.cpp:365; no N mask there), and the window before the seed
+                        // is part of that prefix -- so a candidate that fails both tests needs no reference access at all.
+                        // The location comes with the same round trip, so that a survivor's reference words are one more.
                         const SeedEnt ef = L.ent[eif];
                         const SeedEntGap g = L.entg[eif];
                         uint32_t jj = ef.jj0 + (tf - ef.pre);
                         if (jj >= ef.m) jj -= ef.m;
-                        const uint32_t x = guard_u32(cx, G_LOCS, ef.off + jj, COLD(nlocs), r);
-                        uint64_t fa = cx.flank_a[x], fb = cx.flank_b[x];
-                        uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
-                        uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ef.fr, ef.fc, fa) & ef.fm) + XM64(db & g.bm);
-                        keep = lb <= st.thr || (st.thr >= 2 && XM64(db & g.bin) < st.thr - 1);
+                        const uint32_t x = guard_u32(cx, G_LOCS, ef.off + jj, nlocs_u, r);
+                        const uint32_t loc_raw = cx.locs[x];
+                        const uint64_t fa = cx.flank_a[x], fb = cx.flank_b[x];
+                        uint32_t lc = loc_raw - ef.h();
+                        if (((unsigned long long)(lc >> 5) + NWT + 4) >= COLD(nwords)) lc = (uint32_t)guard_idx(cx, G_XREF, lc, 0, r) + BASAL_REF_MARGIN * 32;
+                        const uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
+                        const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ef.fr, ef.fc, fa) & ef.fm) + XM64(db & g.bm);
+                        const bool al = lb <= st.thr, gk = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
+                        keep = al || gk;
+                        sv.loc = lc;
+                        sv.meta = eif | ((uint32_t)(jj >= ef.nfwd) << 8) | ((uint32_t)al << 9) | ((uint32_t)gk << 10);
                     }
+                    PH(PH_FILTER);
                     uint64_t mk = ballot(keep);
-                    if (keep) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = tf;
+                    if (keep) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
                     nsurv += (uint32_t)__popcll(mk);
                     t0 += 64;
                     wave_sync();
@@ -1036,7 +1047,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 batch = nsurv < 64 ? nsurv : 64;
                 if (batch == 0) continue;
                 active = (uint32_t)lane < batch;
-                t = active ? L.surv[lane] : 0;
+                t = 0;
             } else {
                 t = t0 + lane;
                 active = t < T;
@@ -1045,10 +1056,41 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             // which seed's list candidate t belongs to = the number of list ends (inc[e], e < nent-1) that are <= t.
             // Non-GAP: the chunk is 64 consecutive t, so that is the count at t0 plus the ends inside the chunk (one
             // or two, typically) -- cheaper than comparing every lane against every end.
-            uint32_t ei = 0;
+            uint32_t ei = 0, loc = 0, strand = 0, mm = 0xffff, hcs = 0;
+            bool gap_ok = false;  // GAP: the flank tests leave the gap search a chance
+            uint64_t W[GAP ? NWT + 2 : 1], D0[GAP ? NWT : 1];  // GAP: the candidate's reference words and ungapped mismatch bitmap
+            uint32_t rel0 = 0;
             if (GAP) {
-                for (uint32_t e = 0; e + 1 < nent; e++) ei += (t >= rdlane(inc, (int)e));
+                // one round trip fetches the reference words of all 2g+1 start positions; the ungapped count (the bitmap under
+                // the valid mask, plus the N count) and the gap search both work from these registers
+                bool alive = false;
+                if (active) {
+                    const SurvEnt sv = L.surv[lane];
+                    ei = sv.meta & 0xff;
+                    strand = (sv.meta >> 8) & 1;
+                    alive = (sv.meta >> 9) & 1;
+                    gap_ok = (sv.meta >> 10) & 1;
+                    loc = sv.loc;
+                    hcs = L.ent[ei].hcs;
+                }
+                const uint64_t(*qg)[NWT + 1] = L.q[(hcs >> 16) & 1];
+                const uint32_t first = loc - cx.gap;  // loc >= 12320 by construction
+                rel0 = (first & 31) + cx.gap;
+                if (active) {
+                    const uint64_t *sp = cx.xref[strand] + (first >> 5);
+#pragma unroll
+                    for (int i = 0; i < NWT + 2; i++) W[i] = (uint32_t)i <= rc.end_element + 2 ? sp[i] : 0;
+                    mismatch_map_regs<NWT, NEWRULE>(W, rel0, qg, rc.end_element, rc.end_offset, D0);
+                    if (alive) {
+                        mm = rc.n_count;
+#pragma unroll
+                        for (int i = 0; i < NWT; i++) mm += popc64(D0[i] & qg[1][i] & kPairLo);
+                    }
+                }
             } else {
+                // which seed's list candidate t belongs to = the number of list ends (inc[e], e < nent-1) that are <= t.
+                // The chunk is 64 consecutive t, so that is the count at t0 plus the ends inside the chunk (one
+                // or two, typically) -- cheaper than comparing every lane against every end.
                 const uint32_t tb = t0 - 64;  // this chunk's first t (t0 has been advanced)
                 const bool is_end = (uint32_t)lane + 1 < nent;
                 ei = (uint32_t)__popcll(ballot(is_end && inc <= tb));
@@ -1059,47 +1101,34 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     ei += ((uint32_t)lane >= rdlane(inc, en) - tb);
                 }
             }
-            SeedEnt e = L.ent[active ? ei : 0];
-            uint32_t loc = 0, strand = 0, mm = 0xffff;
-            bool gap_ok = false;  // GAP: the flank tests leave the gap search a chance
-            const uint64_t(*q)[NWT + 1] = L.q[e.chain()];
-            if (active) {
-                uint32_t jj = e.jj0 + (t - e.pre);
-                if (jj >= e.m) jj -= e.m;
-                // kmer_off is 32-bit, so list positions are too
-                const uint32_t ei_ = guard_u32(cx, G_LOCS, e.off + jj, nlocs_u, r);
-                // the location and the flank word(s) are requested together, before the location is looked at (its bounds
-                // check branches, and a load placed after the branch would cost a second memory round trip per chunk)
-                const uint32_t loc_raw = cx.locs[ei_];
-                uint64_t f = 0, fa = 0, fb = 0;
-                if (!GAP) f = cx.flank_a[(unsigned long long)ei_ + (e.side() ? flank_b_off : 0ULL)];
-                else { fa = cx.flank_a[ei_]; fb = cx.flank_b[ei_]; }
-                loc = loc_raw - e.h();
-                if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
-                strand = jj >= e.nfwd;
-                bool alive = true;
-                if (!GAP) {  // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
-                    uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, f) & e.fm);
-                    alive = lb <= st.thr;
+            const uint64_t(*q)[NWT + 1] = L.q[0];
+            if (!GAP) {
+                const SeedEnt e = L.ent[active ? ei : 0];
+                hcs = e.hcs;
+                q = L.q[e.chain()];
+                if (active) {
+                    uint32_t jj = e.jj0 + (t - e.pre);
+                    if (jj >= e.m) jj -= e.m;
+                    // kmer_off is 32-bit, so list positions are too
+                    const uint32_t ei_ = guard_u32(cx, G_LOCS, e.off + jj, nlocs_u, r);
+                    // the location and the flank word are requested together, before the location is looked at (its bounds
+                    // check branches, and a load placed after the branch would cost a second memory round trip per chunk)
+                    const uint32_t loc_raw = cx.locs[ei_];
+                    const uint64_t f = cx.flank_a[(unsigned long long)ei_ + (e.side() ? flank_b_off : 0ULL)];
+                    loc = loc_raw - e.h();
+                    if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
+                    strand = jj >= e.nfwd;
+                    // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
+                    const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, f) & e.fm);
+                    const bool alive = lb <= st.thr;
                     PH(PH_FILTER);
-                } else {
-                    // both flanks: the ungapped count is at least the two windows' mismatches; the gap search gives up at
-                    // once when the read prefix up to the seed end already holds thr-1 mismatches (MismatchPattern0's
-                    // return value vs seed_pos+seed_size, align.cpp:365; no N mask there), and the window before the seed
-                    // is part of that prefix -- so a candidate that fails both tests needs no reference access at all
-                    const SeedEntGap g = L.entg[ei];
-                    uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
-                    uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, fa) & e.fm) + XM64(db & g.bm);
-                    alive = lb <= st.thr;
-                    gap_ok = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
-                    PH(PH_FILTER);
+                    if (alive) {
+                        uint32_t off2 = (loc & 31) * 2;
+                        uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
+                        mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
+                    }
                 }
-                if (alive) {
-                    uint32_t off2 = (loc & 31) * 2;
-                    uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
-                    mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
-                }
-            }
+            } else q = L.q[(hcs >> 16) & 1];
             PH(PH_SCORE);
             uint64_t act = ballot(active);
             uint64_t ung_pending = act, gap_pending = GAP ? (act & ballot(gap_ok)) : 0;
@@ -1111,7 +1140,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 if (GAP) {
                     bool mine = (gap_pending >> lane) & 1;
                     gfound = false;
-                    if (mine) gfound = gap_align<NWT, NEWRULE>(cx, cx.xref[strand], loc, q, rc, st.thr, e.h(), gsnp, gpos, gshift);
+                    if (mine) gfound = gap_align<NWT, NEWRULE>(cx, W, rel0, D0, q, rc, st.thr, hcs & 0xffffu, gsnp, gpos, gshift);
                 }
                 uint64_t acc = ballot(active && mm <= st.thr) & ung_pending;
                 uint64_t gm = GAP ? (ballot(gfound) & gap_pending) : 0;
@@ -1120,7 +1149,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     int l = __ffsll((unsigned long long)(acc | gm)) - 1;
                     uint64_t bit = 1ULL << l;
                     uint32_t thr_before = st.thr;
-                    uint32_t lloc = rdlane(loc, l), lstrand = rdlane(strand, l), lchain = rdlane(e.chain(), l);
+                    uint32_t lloc = rdlane(loc, l), lstrand = rdlane(strand, l), lchain = rdlane((hcs >> 16) & 1, l);
                     if (acc & bit) {
                         acc &= ~bit;
                         ung_pending &= ~bit;
@@ -1151,7 +1180,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             PH(PH_REPLAY);
             if (GAP) {  // drop the processed batch from the front of the list
                 uint32_t rest = nsurv - batch;
-                uint32_t v = (uint32_t)lane < rest ? L.surv[batch + lane] : 0;
+                SurvEnt v = {0, 0};
+                if ((uint32_t)lane < rest) v = L.surv[batch + lane];
                 wave_sync();
                 if ((uint32_t)lane < rest) L.surv[lane] = v;
                 nsurv = rest;
