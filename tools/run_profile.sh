@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-end evidence on the GPU box:  gpurun -- 'bash tools/run_profile.sh r01'
+#   1. python3 bench.py (default flags) plain                        -> gpurun_out/<tag>_bench_noprof.json
+#   2. the same command under rocprofv3 --kernel-trace --stats       -> gpurun_out/<tag>_bench.json + kernel stats
+#   3. tools/run_pmc.sh (counter passes, --cpu-sample 0 --steps 4)   -> gpurun_out/pmc_<tag>.csv
+set -e
+TAG=${1:-r01}
+ROOT=$(pwd)
+export TMPDIR=/tmp
+python3 bench.py > gpurun_out/${TAG}_bench_noprof.json 2> gpurun_out/${TAG}_bench_noprof.err
+echo "[profile] plain bench done: $(cut -c80-140 gpurun_out/${TAG}_bench_noprof.json)"
+cd /tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_$TAG" -- python3 "$ROOT/bench.py" > "$ROOT/gpurun_out/${TAG}_bench.json" 2> "$ROOT/gpurun_out/${TAG}_bench.err"
+cd "$ROOT"
+echo "[profile] kernel-trace bench done: $(cut -c80-140 gpurun_out/${TAG}_bench.json)"
+grep -h "align_kernel\|fill_flanks\|emit_pairs\|split_counts" gpurun_out/prof_$TAG/*/*kernel_stats.csv | cut -c1-60,150-400 || true
+bash tools/run_pmc.sh $TAG 2>&1 | grep -v "^    @"
