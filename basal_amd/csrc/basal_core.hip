@@ -1258,7 +1258,21 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
 #ifndef BASAL_W4G
 #define BASAL_W4G 4
 #endif
-constexpr int waves_per_simd(int nwt, bool gap) { return nwt == 4 ? (gap ? BASAL_W4G : BASAL_W4NG) : nwt == 8 ? (gap ? 3 : 5) : (gap ? 2 : 3); }
+#ifndef BASAL_W8NG
+#define BASAL_W8NG 5
+#endif
+#ifndef BASAL_W8G
+#define BASAL_W8G 4
+#endif
+#ifndef BASAL_W16NG
+#define BASAL_W16NG 4
+#endif
+#ifndef BASAL_W16G
+#define BASAL_W16G 2
+#endif
+constexpr int waves_per_simd(int nwt, bool gap) {
+    return nwt == 4 ? (gap ? BASAL_W4G : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : BASAL_W8NG) : (gap ? BASAL_W16G : BASAL_W16NG);
+}
 
 template <int NWT, bool NEWRULE, bool GAP>
 __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(DevCtx cx) {

@@ -98,6 +98,13 @@ FIXTURES = {
     "long_400_multi": (["--ref-bp", "300000", "--contigs", "2", "--reads", "100", "-M", "A:CGT", "--p-conv", "0.2", "--len", "400",
                         "--max-sub", "8"],
                        ["-M", "A:CGT", "-S", "1", "-s", "14", "-v", "0.04"]),
+    # read lengths straddling the kernel instantiation bounds (128 / 256 bases), mixed in one batch
+    "len_bound_128": (["--ref-bp", "300000", "--contigs", "2", "--reads", "240", "-M", "C:T", "--len", "136", "--len-jitter", "16",
+                       "--max-sub", "4"],
+                      ["-M", "C:T", "-S", "1", "-s", "12"]),
+    "len_bound_256_g1": (["--ref-bp", "300000", "--contigs", "2", "--reads", "160", "-M", "T:-", "--p-conv", "0.02", "--len", "264", "--len-jitter", "16",
+                          "--max-sub", "5", "--indel-frac", "0.3", "--indel-max", "1"],
+                         ["-M", "T:-", "-S", "1", "-s", "12", "-g", "1", "-n", "1"]),
     # edge cases: reads around the minimum length, lower-case and IUPAC read bases, hidden -N (N counts as a mismatch)
     "edge_short": (["--ref-bp", "200000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--len", "40", "--len-jitter", "30",
                     "--max-sub", "1", "--lower-reads-frac", "0.3", "--iupac-frac", "0.3"],
