@@ -791,8 +791,8 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     if ((int)l < 0) return 0;
     if (l + rc.len > csize) return 0;
     uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
-    bool dup = (uint32_t)lane < st.nlog && hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key;
-    if (ballot(dup)) return 0;
+    const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
+    if (ballot(hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key) & in_regs) return 0;
     for (uint32_t base = 64; base < st.nlog; base += 64) {  // long logs: scan the part in memory
         bool d = false;
         if (base + lane < st.nlog) {
@@ -999,6 +999,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         // cannot rule out are compacted (order kept) into L.surv and scored + gap-searched 64 at a time, so the expensive
         // part runs on full waves instead of on the ~quarter of the lanes that survive.
         const uint64_t lt = (1ULL << lane) - 1;
+        const uint64_t end_mask = nent > 1 ? (1ULL << (nent - 1)) - 1 : 0;  // lanes holding a list end that counts (e < nent - 1)
         const uint32_t nlocs_u = COLD(nlocs);
         const unsigned long long flank_b_off = (unsigned long long)nlocs_u + 64;  // flank_b = flank_a + nlocs + 64
         uint32_t nsurv = 0, batch = 0;
@@ -1008,10 +1009,10 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             if (GAP) {
                 if (t0 < T && nsurv < 64) {
                     const uint32_t tf = t0 + lane;
-                    const bool af = tf < T, is_end = (uint32_t)lane + 1 < nent;
+                    const bool af = tf < T;
                     bool keep = false;
-                    uint32_t eif = (uint32_t)__popcll(ballot(is_end && inc <= t0));  // the list tf belongs to (as below)
-                    for (uint64_t inside = ballot(is_end && inc > t0 && inc - t0 < 64); inside; inside &= inside - 1)
+                    uint32_t eif = (uint32_t)__popcll(ballot(inc <= t0) & end_mask);  // the list tf belongs to (as below)
+                    for (uint64_t inside = ballot(inc - t0 - 1 < 63u) & end_mask; inside; inside &= inside - 1)
                         eif += ((uint32_t)lane >= rdlane(inc, __ffsll((unsigned long long)inside) - 1) - t0);
                     SurvEnt sv = {0, 0};
                     if (af) {
@@ -1092,9 +1093,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 // The chunk is 64 consecutive t, so that is the count at t0 plus the ends inside the chunk (one
                 // or two, typically) -- cheaper than comparing every lane against every end.
                 const uint32_t tb = t0 - 64;  // this chunk's first t (t0 has been advanced)
-                const bool is_end = (uint32_t)lane + 1 < nent;
-                ei = (uint32_t)__popcll(ballot(is_end && inc <= tb));
-                uint64_t inside = ballot(is_end && inc > tb && inc - tb < 64);
+                // (a ballot of one compare is one v_cmp; of a conjunction it is v_cndmask + v_cmp on top: AND the masks instead)
+                ei = (uint32_t)__popcll(ballot(inc <= tb) & end_mask);
+                uint64_t inside = ballot(inc - tb - 1 < 63u) & end_mask;  // tb < inc < tb + 64
                 while (inside) {
                     int en = __ffsll((unsigned long long)inside) - 1;
                     inside &= inside - 1;
@@ -1142,7 +1143,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     gfound = false;
                     if (mine) gfound = gap_align<NWT, NEWRULE>(cx, W, rel0, D0, q, rc, st.thr, hcs & 0xffffu, gsnp, gpos, gshift);
                 }
-                uint64_t acc = ballot(active && mm <= st.thr) & ung_pending;
+                uint64_t acc = ballot(mm <= st.thr) & ung_pending;  // ung_pending holds active lanes only
                 uint64_t gm = GAP ? (ballot(gfound) & gap_pending) : 0;
                 bool recompute = false;
                 while (acc | gm) {
@@ -1156,7 +1157,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         uint32_t lmm = rdlane(mm, l);
                         if (add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane)) { done = true; break; }
                         if (st.thr != thr_before) {
-                            acc = ballot(active && mm <= st.thr) & acc;
+                            acc = ballot(mm <= st.thr) & acc;
                             if (GAP) { gap_pending &= ~(bit - 1); recompute = true; break; }
                         }
                     }
@@ -1168,7 +1169,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         thr_before = st.thr;
                         if (add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lsnp, mode, lsh, lgp, lane)) { done = true; break; }
                         if (st.thr != thr_before) {
-                            acc = ballot(active && mm <= st.thr) & acc;
+                            acc = ballot(mm <= st.thr) & acc;
                             gap_pending &= ~((bit << 1) - 1);
                             recompute = true;
                             break;
