@@ -1,4 +1,5 @@
 """Parity tests proper: the HIP path (through the C ABI) against the oracle and the golden SAMs."""
+import ctypes as C
 import os
 import subprocess
 
@@ -151,3 +152,54 @@ def test_cli_pe_small_batches(name, tmp_path):
     r = subprocess.run([BASAL_BIN, "-a", fq, "-b", fq2, "-d", fa] + H.MANIFEST[name]["flags"] + ["-Z", "50", "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "".join(l for l in open(out) if not l.startswith("@PG")) == H.golden_sam(name)
+
+
+def test_abi_edge_cases():
+    """Empty batch, skipped descriptors, a hit stream that is too small (BASAL_EOVERFLOW, then a retry with the
+    capacity the call reported), a read longer than the batch's longest kernel bound."""
+    name = "rep_r2_w10"
+    fa, fq, _, _ = H.fixture_paths(name)
+    flags = H.MANIFEST[name]["flags"]
+    p = B.Params(H.rule_of(flags), flags)
+    ref = B.Reference(p, fasta_path=fa)
+    ref.build_index(4)
+    core = B.Core(p)
+    core.upload(ref)
+    recs = H.filter_reads(p, orc.read_fastx(fq))[:60]
+    bases, descs, stales = H.make_batch(p, recs, H.StaleTracker(p))
+    # reference result with a roomy stream
+    res, stream, _ = core.align_batch(bases, descs, B.STREAM_BEST, stream_cap=100000, stales=stales)
+    assert len(stream) > 60 and (res["status"] == 0).all()
+    # n = 0
+    r0, s0, _ = core.align_batch(bases[:0], descs[:0], B.STREAM_BEST, stream_cap=16)
+    assert len(r0) == 0 and len(s0) == 0
+    # too small a stream: the call says so and reports what it needed; no record is written past the capacity
+    cap = len(stream) // 2
+    rs = np.zeros(len(descs), B.core.RESULT_DTYPE)
+    st = np.zeros(cap + 8, B.core.HIT_DTYPE)
+    st["loc"][cap:] = 0xDEADBEEF
+    used = C.c_uint64()
+    cy = np.zeros((2, 2), np.uint8)
+    rc = B.core.lib().basal_core_align_batch(core.h, bases.ctypes.data, len(bases), descs.ctypes.data, len(descs),
+                                             stales.ctypes.data if len(stales) else None, len(stales), B.STREAM_BEST,
+                                             rs.ctypes.data, st.ctypes.data, cap, C.byref(used), cy.ctypes.data)
+    assert rc == -5 and used.value == len(stream)                     # BASAL_EOVERFLOW, needed capacity
+    assert (st["loc"][cap:] == 0xDEADBEEF).all()
+    over = rs["status"] == 2                                          # BASAL_READ_OVERFLOW
+    assert over.any() and not over.all()
+    assert np.array_equal(rs["n_hit"], res["n_hit"]) and np.array_equal(rs["best"], res["best"])
+    res2, stream2, _ = core.align_batch(bases, descs, B.STREAM_BEST, stream_cap=int(used.value), stales=stales)
+    # (where a read's records land in the stream depends on the order the waves finish; its records do not)
+    for f in ("best", "n_hit", "n_chit", "best_level", "status", "stream_n"):
+        assert np.array_equal(res2[f], res[f]), f
+    for a, b in zip(res, res2):
+        assert np.array_equal(stream[a["stream_first"]:a["stream_first"] + a["stream_n"]], stream2[b["stream_first"]:b["stream_first"] + b["stream_n"]])
+    # skipped descriptors: len 0 (QC-failed on the host) and a read longer than the longest read announced for the batch
+    d2 = descs.copy()
+    d2["len"][3] = 0
+    res3, _, _ = core.align_batch(bases, d2, B.STREAM_NONE, stales=stales)
+    assert res3["status"][3] == 1 and res3["best_level"][3] == 0xFF   # BASAL_READ_SKIPPED
+    keep = np.ones(len(descs), bool)
+    keep[3] = False
+    # reads after the skipped one may inherit a different start offset only if they are stale-dependent; this fixture has none
+    assert np.array_equal(res3["best"][keep], res["best"][keep])
