@@ -847,6 +847,37 @@ __device__ uint32_t find_kth(const HitState &st, const basal_hit *log, uint32_t 
     return 0xffffffffu;
 }
 
+// The loads of one 64-candidate chunk of a mode's stream (non-GAP kernels), issued one chunk ahead: which list each
+// candidate belongs to, its position in the list, its location and the flank word the filter compares.
+struct ChunkLoads {
+    uint32_t ei, jj, loc_raw;
+    uint64_t f;
+};
+template <class LDS>
+__device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L, uint32_t inc, uint64_t end_mask, uint32_t tb, uint32_t T, int lane,
+                                                  uint32_t nlocs_u, unsigned long long flank_b_off, uint32_t r) {
+    ChunkLoads c = {0, 0, 0, 0};
+    // which seed's list candidate t belongs to = the number of list ends (inc[e], e < nent-1) that are <= t. The chunk is
+    // 64 consecutive t, so that is the count at tb plus the ends inside the chunk (one or two, typically) -- cheaper than
+    // comparing every lane against every end. (A ballot of one compare is one v_cmp; of a conjunction it is
+    // v_cndmask + v_cmp on top: AND the masks instead.)
+    uint32_t ei = (uint32_t)__popcll(ballot(inc <= tb) & end_mask);
+    for (uint64_t inside = ballot(inc - tb - 1 < 63u) & end_mask; inside; inside &= inside - 1)  // tb < inc < tb + 64
+        ei += ((uint32_t)lane >= rdlane(inc, __ffsll((unsigned long long)inside) - 1) - tb);
+    const uint32_t t = tb + (uint32_t)lane;
+    if (t < T) {
+        const uint32_t e_off = L.ent[ei].off, e_m = L.ent[ei].m, e_jj0 = L.ent[ei].jj0, e_pre = L.ent[ei].pre, e_hcs = L.ent[ei].hcs;
+        uint32_t jj = e_jj0 + (t - e_pre);
+        if (jj >= e_m) jj -= e_m;
+        const uint32_t x = guard_u32(cx, G_LOCS, e_off + jj, nlocs_u, r);  // kmer_off is 32-bit, so list positions are too
+        c.loc_raw = cx.locs[x];
+        c.f = cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)];
+        c.ei = ei;
+        c.jj = jj;
+    }
+    return c;
+}
+
 // ---- one read ----------------------------------------------------------------------------------
 template <int NWT, bool NEWRULE, bool GAP>
 __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
@@ -1003,6 +1034,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         const uint32_t nlocs_u = COLD(nlocs);
         const unsigned long long flank_b_off = (unsigned long long)nlocs_u + 64;  // flank_b = flank_a + nlocs + 64
         uint32_t nsurv = 0, batch = 0;
+        ChunkLoads nxt = {0, 0, 0, 0};
+        if (!GAP && T > 0) nxt = issue_chunk(cx, L, inc, end_mask, 0, T, lane, nlocs_u, flank_b_off, r);
         for (uint32_t t0 = 0; (t0 < T || (GAP && nsurv > 0)) && !done;) {
             uint32_t t;
             bool active;
@@ -1088,46 +1121,32 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         for (int i = 0; i < NWT; i++) mm += popc64(D0[i] & qg[1][i] & kPairLo);
                     }
                 }
-            } else {
-                // which seed's list candidate t belongs to = the number of list ends (inc[e], e < nent-1) that are <= t.
-                // The chunk is 64 consecutive t, so that is the count at t0 plus the ends inside the chunk (one
-                // or two, typically) -- cheaper than comparing every lane against every end.
-                const uint32_t tb = t0 - 64;  // this chunk's first t (t0 has been advanced)
-                // (a ballot of one compare is one v_cmp; of a conjunction it is v_cndmask + v_cmp on top: AND the masks instead)
-                ei = (uint32_t)__popcll(ballot(inc <= tb) & end_mask);
-                uint64_t inside = ballot(inc - tb - 1 < 63u) & end_mask;  // tb < inc < tb + 64
-                while (inside) {
-                    int en = __ffsll((unsigned long long)inside) - 1;
-                    inside &= inside - 1;
-                    ei += ((uint32_t)lane >= rdlane(inc, en) - tb);
-                }
             }
             const uint64_t(*q)[NWT + 1] = L.q[0];
             if (!GAP) {
-                const SeedEnt e = L.ent[active ? ei : 0];
-                hcs = e.hcs;
-                q = L.q[e.chain()];
+                // this chunk's location and flank word were requested one chunk ago
+                const ChunkLoads cur = nxt;
+                ei = active ? cur.ei : 0;
+                hcs = L.ent[ei].hcs;
+                q = L.q[(hcs >> 16) & 1];
+                bool alive = false;
                 if (active) {
-                    uint32_t jj = e.jj0 + (t - e.pre);
-                    if (jj >= e.m) jj -= e.m;
-                    // kmer_off is 32-bit, so list positions are too
-                    const uint32_t ei_ = guard_u32(cx, G_LOCS, e.off + jj, nlocs_u, r);
-                    // the location and the flank word are requested together, before the location is looked at (its bounds
-                    // check branches, and a load placed after the branch would cost a second memory round trip per chunk)
-                    const uint32_t loc_raw = cx.locs[ei_];
-                    const uint64_t f = cx.flank_a[(unsigned long long)ei_ + (e.side() ? flank_b_off : 0ULL)];
-                    loc = loc_raw - e.h();
+                    const uint32_t e_nfwd = L.ent[ei].nfwd;
+                    const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm, e_fc = NEWRULE ? L.ent[ei].fc : 0;
+                    loc = cur.loc_raw - (hcs & 0xffffu);
                     if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
-                    strand = jj >= e.nfwd;
+                    strand = cur.jj >= e_nfwd;
                     // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
-                    const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e.fr, e.fc, f) & e.fm);
-                    const bool alive = lb <= st.thr;
+                    const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e_fr, e_fc, cur.f) & e_fm);
+                    alive = lb <= st.thr;
                     PH(PH_FILTER);
-                    if (alive) {
-                        uint32_t off2 = (loc & 31) * 2;
-                        uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
-                        mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
-                    }
+                }
+                // the next chunk's loads go out now and overlap the exact scoring and the replay of this one
+                if (t0 < T) nxt = issue_chunk(cx, L, inc, end_mask, t0, T, lane, nlocs_u, flank_b_off, r);
+                if (alive) {
+                    uint32_t off2 = (loc & 31) * 2;
+                    uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
+                    mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
                 }
             } else q = L.q[(hcs >> 16) & 1];
             PH(PH_SCORE);
