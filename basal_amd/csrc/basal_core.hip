@@ -1126,6 +1126,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             if (!GAP) {
                 // this chunk's location and flank word were requested one chunk ago
                 const ChunkLoads cur = nxt;
+                // the next chunk's loads go out before this one is looked at: they overlap its filter, exact scoring and replay
+                if (t0 < T) nxt = issue_chunk(cx, L, inc, end_mask, t0, T, lane, nlocs_u, flank_b_off, r);
                 ei = active ? cur.ei : 0;
                 hcs = L.ent[ei].hcs;
                 q = L.q[(hcs >> 16) & 1];
@@ -1141,8 +1143,6 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     alive = lb <= st.thr;
                     PH(PH_FILTER);
                 }
-                // the next chunk's loads go out now and overlap the exact scoring and the replay of this one
-                if (t0 < T) nxt = issue_chunk(cx, L, inc, end_mask, t0, T, lane, nlocs_u, flank_b_off, r);
                 if (alive) {
                     uint32_t off2 = (loc & 31) * 2;
                     uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
