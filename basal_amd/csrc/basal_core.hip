@@ -851,12 +851,12 @@ __device__ uint32_t find_kth(const HitState &st, const basal_hit *log, uint32_t 
 // candidate belongs to, its position in the list, its location and the flank word the filter compares.
 struct ChunkLoads {
     uint32_t ei, jj, loc_raw;
-    uint64_t f;
+    uint64_t f, fb;  // non-GAP: f = the flank word on the entry's longer side; GAP: f = after the seed, fb = before it
 };
-template <class LDS>
+template <bool BOTH, class LDS>
 __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L, uint32_t inc, uint64_t end_mask, uint32_t tb, uint32_t T, int lane,
                                                   uint32_t nlocs_u, unsigned long long flank_b_off, uint32_t r) {
-    ChunkLoads c = {0, 0, 0, 0};
+    ChunkLoads c = {0, 0, 0, 0, 0};
     // which seed's list candidate t belongs to = the number of list ends (inc[e], e < nent-1) that are <= t. The chunk is
     // 64 consecutive t, so that is the count at tb plus the ends inside the chunk (one or two, typically) -- cheaper than
     // comparing every lane against every end. (A ballot of one compare is one v_cmp; of a conjunction it is
@@ -871,7 +871,8 @@ __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L
         if (jj >= e_m) jj -= e_m;
         const uint32_t x = guard_u32(cx, G_LOCS, e_off + jj, nlocs_u, r);  // kmer_off is 32-bit, so list positions are too
         c.loc_raw = cx.locs[x];
-        c.f = cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)];
+        if (BOTH) { c.f = cx.flank_a[x]; c.fb = cx.flank_b[x]; }
+        else c.f = cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)];
         c.ei = ei;
         c.jj = jj;
     }
@@ -1034,8 +1035,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         const uint32_t nlocs_u = COLD(nlocs);
         const unsigned long long flank_b_off = (unsigned long long)nlocs_u + 64;  // flank_b = flank_a + nlocs + 64
         uint32_t nsurv = 0, batch = 0;
-        ChunkLoads nxt = {0, 0, 0, 0};
-        if (!GAP && T > 0) nxt = issue_chunk(cx, L, inc, end_mask, 0, T, lane, nlocs_u, flank_b_off, r);
+        ChunkLoads nxt = {0, 0, 0, 0, 0};
+        if (T > 0) nxt = issue_chunk<GAP>(cx, L, inc, end_mask, 0, T, lane, nlocs_u, flank_b_off, r);
         for (uint32_t t0 = 0; (t0 < T || (GAP && nsurv > 0)) && !done;) {
             uint32_t t;
             bool active;
@@ -1044,9 +1045,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     const uint32_t tf = t0 + lane;
                     const bool af = tf < T;
                     bool keep = false;
-                    uint32_t eif = (uint32_t)__popcll(ballot(inc <= t0) & end_mask);  // the list tf belongs to (as below)
-                    for (uint64_t inside = ballot(inc - t0 - 1 < 63u) & end_mask; inside; inside &= inside - 1)
-                        eif += ((uint32_t)lane >= rdlane(inc, __ffsll((unsigned long long)inside) - 1) - t0);
+                    // this chunk's location and flank words were requested one chunk ago; the next chunk's go out now
+                    const ChunkLoads cur = nxt;
+                    if (t0 + 64 < T) nxt = issue_chunk<true>(cx, L, inc, end_mask, t0 + 64, T, lane, nlocs_u, flank_b_off, r);
                     SurvEnt sv = {0, 0};
                     if (af) {
                         // both flanks: the ungapped count is at least the two windows' mismatches; the gap search gives up at
@@ -1054,21 +1055,18 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         // return value vs seed_pos+seed_size, align.cpp:365; no N mask there), and the window before the seed
                         // is part of that prefix -- so a candidate that fails both tests needs no reference access at all.
                         // The location comes with the same round trip, so that a survivor's reference words are one more.
-                        const SeedEnt ef = L.ent[eif];
+                        const uint32_t eif = cur.ei;
+                        const uint32_t e_hcs = L.ent[eif].hcs, e_nfwd = L.ent[eif].nfwd;
+                        const uint64_t e_fr = L.ent[eif].fr, e_fm = L.ent[eif].fm, e_fc = NEWRULE ? L.ent[eif].fc : 0;
                         const SeedEntGap g = L.entg[eif];
-                        uint32_t jj = ef.jj0 + (tf - ef.pre);
-                        if (jj >= ef.m) jj -= ef.m;
-                        const uint32_t x = guard_u32(cx, G_LOCS, ef.off + jj, nlocs_u, r);
-                        const uint32_t loc_raw = cx.locs[x];
-                        const uint64_t fa = cx.flank_a[x], fb = cx.flank_b[x];
-                        uint32_t lc = loc_raw - ef.h();
+                        uint32_t lc = cur.loc_raw - (e_hcs & 0xffffu);
                         if (((unsigned long long)(lc >> 5) + NWT + 4) >= COLD(nwords)) lc = (uint32_t)guard_idx(cx, G_XREF, lc, 0, r) + BASAL_REF_MARGIN * 32;
-                        const uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, fb);
-                        const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ef.fr, ef.fc, fa) & ef.fm) + XM64(db & g.bm);
+                        const uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, cur.fb);
+                        const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e_fr, e_fc, cur.f) & e_fm) + XM64(db & g.bm);
                         const bool al = lb <= st.thr, gk = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
                         keep = al || gk;
                         sv.loc = lc;
-                        sv.meta = eif | ((uint32_t)(jj >= ef.nfwd) << 8) | ((uint32_t)al << 9) | ((uint32_t)gk << 10);
+                        sv.meta = eif | ((uint32_t)(cur.jj >= e_nfwd) << 8) | ((uint32_t)al << 9) | ((uint32_t)gk << 10);
                     }
                     PH(PH_FILTER);
                     uint64_t mk = ballot(keep);
@@ -1127,7 +1125,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 // this chunk's location and flank word were requested one chunk ago
                 const ChunkLoads cur = nxt;
                 // the next chunk's loads go out before this one is looked at: they overlap its filter, exact scoring and replay
-                if (t0 < T) nxt = issue_chunk(cx, L, inc, end_mask, t0, T, lane, nlocs_u, flank_b_off, r);
+                if (t0 < T) nxt = issue_chunk<false>(cx, L, inc, end_mask, t0, T, lane, nlocs_u, flank_b_off, r);
                 ei = active ? cur.ei : 0;
                 hcs = L.ent[ei].hcs;
                 q = L.q[(hcs >> 16) & 1];
