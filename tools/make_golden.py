@@ -98,6 +98,12 @@ FIXTURES = {
     "long_400_multi": (["--ref-bp", "300000", "--contigs", "2", "--reads", "100", "-M", "A:CGT", "--p-conv", "0.2", "--len", "400",
                         "--max-sub", "8"],
                        ["-M", "A:CGT", "-S", "1", "-s", "14", "-v", "0.04"]),
+    # a wide index interval: 2I = 24 (chain, phase) seeds per mode (the > 16-entry scan path), few seed segments
+    "I12": (["--ref-bp", "300000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--len", "120", "--len-jitter", "30", "--max-sub", "3"],
+            ["-M", "C:T", "-S", "1", "-s", "12", "-I", "12", "-n", "1"]),
+    "I16_g1": (["--ref-bp", "300000", "--contigs", "2", "--reads", "200", "-M", "A:G", "--p-conv", "0.7", "--len", "150", "--max-sub", "3",
+                "--indel-frac", "0.2", "--indel-max", "1"],
+               ["-M", "A:G", "-S", "1", "-s", "12", "-I", "16", "-g", "1"]),
     # read lengths straddling the kernel instantiation bounds (128 / 256 bases), mixed in one batch
     "len_bound_128": (["--ref-bp", "300000", "--contigs", "2", "--reads", "240", "-M", "C:T", "--len", "136", "--len-jitter", "16",
                        "--max-sub", "4"],
