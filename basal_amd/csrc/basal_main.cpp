@@ -38,6 +38,29 @@ struct Reader {  // whole file in memory; iostream-token semantics of ReadClass:
         size_t p = 0;
         while (p < buf.size() && ws((unsigned char)buf[p])) p++;
         fastq = p < buf.size() && buf[p] == '@';
+        // BAM (main.cpp:386-405 tries FASTA, FASTQ, then BAM): BGZF is multi-member gzip, so buf already holds the
+        // uncompressed stream -- magic, header text, reference table, then the alignment records
+        if (buf.size() >= 12 && memcmp(buf.data(), "BAM\1", 4) == 0) {
+            bam = true;
+            size_t q = 4;
+            int32_t l_text = i32(q); q += 4 + (size_t)l_text;
+            if (q + 4 > buf.size()) return false;
+            int32_t n_ref = i32(q); q += 4;
+            for (int32_t k = 0; k < n_ref && q + 4 <= buf.size(); k++) { int32_t l_name = i32(q); q += 4 + (size_t)l_name + 4; }
+            if (q > buf.size()) return false;
+            pos = q;
+        }
+        return true;
+    }
+    bool bam = false;
+    int32_t i32(size_t at) const { int32_t v; memcpy(&v, buf.data() + at, 4); return v; }
+    // next BAM record: [at, at + 4 + block_size); false at the end of the file
+    bool bam_next(size_t &at) {
+        if (pos + 4 > buf.size()) return false;
+        int32_t bs = i32(pos);
+        if (bs < 32 || pos + 4 + (size_t)bs > buf.size()) return false;
+        at = pos + 4;
+        pos += 4 + (size_t)bs;
         return true;
     }
     void skip_ws() { while (pos < buf.size() && ws((unsigned char)buf[pos])) pos++; }
@@ -61,7 +84,43 @@ struct Rec {
     uint32_t max_snp = 0;
 };
 
+// BAM records (reads.cpp:84-110): name, 4-bit bases, phred + 33; with -b the two mates alternate in one file
+// (mate 1 reads a record and skips one, mate 2 skips one and reads), and flags 0x40 / 0x80 name the mate
+int load_batch_bam(Reader &r, const basal_params &p, uint32_t read_end, size_t want, int readset, std::vector<Rec> &out) {
+    static const char nt16[] = "=ACMGRSVTWYHKDBN";
+    out.clear();
+    for (; out.size() < want && r.index < read_end; r.index++) {
+        size_t at, skip;
+        if (readset == 2 && !r.bam_next(skip)) break;
+        if (!r.bam_next(at)) break;
+        const unsigned char *b = (const unsigned char *)r.buf.data() + at;
+        uint32_t l_name = b[8], n_cigar, flag, l_qseq;
+        uint16_t u16;
+        memcpy(&u16, b + 12, 2); n_cigar = u16;
+        memcpy(&u16, b + 14, 2); flag = u16;
+        memcpy(&l_qseq, b + 16, 4);
+        const char *name = (const char *)b + 32;
+        const unsigned char *sq = b + 32 + l_name + 4 * n_cigar, *ql = sq + (l_qseq + 1) / 2;
+        if (ql + l_qseq > (const unsigned char *)r.buf.data() + r.pos) break;  // truncated record
+        uint32_t l = std::min<uint32_t>(l_qseq, p.max_readlen);
+        Rec o;
+        o.index = r.index;
+        o.readset = readset ? ((flag & 0x40) ? 1u : (flag & 0x80) ? 2u : (uint32_t)readset) : 0u;
+        o.name.assign(name, strnlen(name, l_name));
+        o.seq.assign((size_t)l + 2, 0);
+        o.qual.assign((size_t)l + 2, 0);
+        for (uint32_t i = 0; i < l; i++) {
+            o.seq[i] = nt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xf];
+            o.qual[i] = (char)(ql[i] + 33);
+        }
+        if (readset == 1 && !r.bam_next(skip)) break;  // (the reference drops a mate 1 without a following record, too)
+        out.push_back(std::move(o));
+    }
+    return (int)out.size();
+}
+
 int load_batch(Reader &r, const basal_params &p, uint32_t read_end, size_t want, int readset, std::vector<Rec> &out) {
+    if (r.bam) return load_batch_bam(r, p, read_end, want, readset, out);
     out.clear();
     for (; out.size() < want && r.index < read_end; r.index++) {
         r.skip_ws();

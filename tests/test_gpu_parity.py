@@ -203,3 +203,27 @@ def test_abi_edge_cases():
     keep[3] = False
     # reads after the skipped one may inherit a different start offset only if they are stale-dependent; this fixture has none
     assert np.array_equal(res3["best"][keep], res["best"][keep])
+
+
+@pytest.mark.parametrize("name", [n for n, m in H.MANIFEST.items() if m.get("bam_input_checked")])
+def test_cli_bam_input(name, tmp_path):
+    """`-a reads.bam` (and `-a x.bam -b x.bam` with the mates interleaved): tools/make_golden.py checked that the reference
+    prints the golden SAM for the BAM form of these reads too (reads.cpp:84-110), so the CLI's BAM reader must as well."""
+    import gzip
+    import sys
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    pe = H.MANIFEST[name]["pe"]
+    plain = []
+    for i, f in enumerate([fq] + ([fq2] if pe else [])):
+        p = tmp_path / ("r%d.fq" % i)
+        p.write_bytes(gzip.open(f, "rb").read() if str(f).endswith(".gz") else open(f, "rb").read())
+        plain.append(str(p))
+    bam = str(tmp_path / "reads.bam")
+    subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fq2bam.py"), plain[0], bam] + plain[1:], check=True)
+    out = tmp_path / "o.sam"
+    env = dict(os.environ, BASAL_CPU_INDEX="1")
+    r = subprocess.run([BASAL_BIN, "-a", bam] + (["-b", bam] if pe else []) + ["-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "4", "-o", str(out)],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)

@@ -219,11 +219,11 @@ def main(argv=None):
             k = int(rng.integers(1, 8))
             m1 = m1.copy()
             m1[rng.choice(m1.size, size=k, replace=False)] = ord("N")
-        if rng.random() < args.iupac_frac:
+        if args.iupac_frac > 0 and rng.random() < args.iupac_frac:  # (no draw when the option is off: older fixtures stay reproducible)
             m1 = m1.copy()
             for q in rng.choice(m1.size, size=int(rng.integers(1, 4)), replace=False):
                 m1[q] = b"RYKMSW"[int(rng.integers(0, 6))]
-        if rng.random() < args.lower_reads_frac:
+        if args.lower_reads_frac > 0 and rng.random() < args.lower_reads_frac:
             m1 = m1 | 0x20
         emit(f1, tag, revcomp(m1) if args.pbat else m1)
         if pe:

@@ -150,6 +150,9 @@ def gz_write(path, data):
             f.write(data)
 
 
+BAM_CHECK = {"ct_basic", "varlen_trim", "ct_n1_dirty", "pe_ct_100_u", "pe_dirty_r1"}
+
+
 def run(cmd, **kw):
     r = subprocess.run(cmd, **kw)
     if r.returncode != 0:
@@ -190,6 +193,17 @@ def main():
                 nrec = sum(1 for l in body.splitlines() if not l.startswith(b"@"))
                 manifest[name] = {"gen": gen_args, "flags": flags, "pe": pe, "records": nrec,
                                   "reads_file": name + (".reads.fa.gz" if fasta_reads else ".fq.gz")}
+                if name in BAM_CHECK:
+                    # the same reads as an unaligned BAM (mates interleaved for PE): the reference must print the same SAM, so the
+                    # golden SAM also pins the CLI's BAM reader (tests convert the FASTQ with the same tool)
+                    bam = os.path.join(td, name + ".bam")
+                    run([sys.executable, os.path.join(ROOT, "tools", "fq2bam.py"), fq, bam] + ([fq2] if pe else []))
+                    sam2 = os.path.join(td, name + ".bam.sam")
+                    run([REF_BIN, "-a", bam] + (["-b", bam] if pe else []) + ["-d", fa] + flags + ["-p", "1", "-o", sam2],
+                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    if b"".join(l for l in open(sam2, "rb") if not l.startswith(b"@PG")) != body:
+                        raise SystemExit("%s: the reference prints a different SAM for the BAM form of the reads" % name)
+                    manifest[name]["bam_input_checked"] = True
                 print("%-16s %5d records  flags: %s" % (name, nrec, " ".join(flags)))
     json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
 
