@@ -26,10 +26,11 @@ CONFIGS = {
 }
 
 
-def setup(name, scale=0.02):
+def setup(name, scale=0.02, n_reads=None):
     import torch
     import synth_gpu
     rule, flags, rl, n, pconv, sub = CONFIGS[name]
+    n = n_reads or n
     dev = torch.device("cuda", 0)
     p = B.Params(rule, flags)
     G = synth_gpu.make_genome(p, dev, scale=scale, seed=3)
@@ -113,3 +114,21 @@ def test_read_order_independence():
     perm = np.random.default_rng(5).permutation(n)
     res_p = run(core, hb, descs[perm])
     assert res_p.tobytes() == res[perm].tobytes()
+
+
+def test_full_size_properties():
+    """BASELINE.json config 2 at its full genome size (hg38-sized stand-in, 3.09 Gbp, 1.5 G index entries) and 2 M reads:
+    too large for the oracle to check read by read, so the size-independent properties carry it -- planted positions are
+    recovered, strands are right, batching does not matter, a second run is identical.  (bench.py checks a 400 000-read
+    sample of the same workload against the oracle on every default run.)"""
+    p, flags, G, words, sizes, core, hb, descs, (ci, start, rev) = setup("c2_ct_g0", scale=1.0, n_reads=2_000_000)
+    res = run(core, hb, descs)
+    aligned = res["best_level"] != 0xFF
+    assert aligned.mean() > 0.999
+    uniq = aligned & (res["n_hit"].astype(np.uint32) + res["n_chit"] == 1)
+    assert uniq.mean() > 0.99
+    ok = (res["best"]["chr"] >> 1 == ci) & (res["best"]["loc"] == start)
+    assert ok[uniq].mean() > 0.999
+    assert ((res["best"]["chr"] & 1) == rev)[uniq & ok].all()
+    assert run(core, hb, descs, split=333_333).tobytes() == res.tobytes()
+    assert run(core, hb, descs).tobytes() == res.tobytes()
