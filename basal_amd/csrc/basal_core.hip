@@ -1,19 +1,24 @@
 // basal_core.hip -- the GPU core of the BASAL seed-and-extend path for MI355X (gfx950 / CDNA4).
 //
-// One read per 64-lane wavefront, persistent waves pulling reads from an atomic queue.
+// One read per 64-lane wavefront, persistent waves pulling chunks of 8 reads from an atomic queue (descriptors in with
+// one load, results out with one store, each read's bytes requested while the read before it is aligned).
 // For each read a wave
 //   1. packs the read into 2-bit planes with wave ballots          (ConvertBina(r)ySeq, align.cpp:79-226)
-//   2. hashes every 3-letter seed and gathers its index count      (xseed_array + CountSeeds' index2[].n[0])
-//   3. orders the seed segments                                    (ReorderSeed/AdjustSeedStartArray, align.cpp:468-540)
-//   4. per mode, fans the candidate locations of all phases out over the lanes, 64 at a time:
-//      coalesced loads of the location list, one gather of reference words per lane,
-//      XOR/AND + popcount scoring                                  (SnpAlign/CountMismatch*, align.cpp:274-316, align.h:118-239)
+//   2. hashes the 3-letter seeds that can be asked for and gathers their index counts
+//                                                                  (xseed_array + CountSeeds' index2[].n[0])
+//   3. orders the seed segments from a CountSeeds(n, start) table  (ReorderSeed/AdjustSeedStartArray, align.cpp:468-540)
+//   4. per mode, fans the candidate locations of all phases out over the lanes, 64 at a time, their loads issued one
+//      chunk ahead: coalesced location + flank words, a conversion-tolerant flank pre-filter (a lower bound of the
+//      mismatch count), one gather of reference words per surviving lane, XOR/AND + popcount scoring
+//                                                                  (SnpAlign/CountMismatch*, align.cpp:274-316, align.h:118-239)
 //      and the bit-parallel single-gap search                      (GapAlign/MismatchPattern*, align.cpp:348-410)
 //   5. replays the accepted candidates IN VISITATION ORDER through the sequential hit state
 //      machine (bounds, de-dup, per-level cap, threshold tightening; AddHit align.h:329-347,
-//      int2hit align.cpp:319-346), which is what makes the result bit-identical
+//      int2hit align.cpp:319-346), which is what makes the result bit-identical; the first 64 hits of a read
+//      live in registers
 //   6. selects what StringAlign (align.cpp:583-612) would print.
-// All arithmetic is integer/bitwise; the kernel is bound by HBM/L2 gathers, not ALU (no MFMA).
+// All arithmetic is integer/bitwise (no MFMA). DESIGN.md section 4.1 has the measurements: memory gathers, instruction
+// issue and per-read latency all bound it about equally.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
