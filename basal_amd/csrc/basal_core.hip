@@ -495,12 +495,14 @@ __device__ void reorder_seed(const DevCtx &cx, LDS &L, const ReadCtx &rc, int la
             uint32_t ptr = (i % 2 == 0) ? i / 2 : rc.nseg - 1 - i / 2;
             uint32_t start = (ptr == 0) ? 0 : rdlane(sa, (int)ptr - 1);
             uint32_t end = (ptr == rc.nseg - 1) ? max_offset : rdlane(sa, (int)ptr + 1);
-            uint32_t cand = start + lane;
-            bool valid = cand <= end && lane < 16;
-            uint32_t tt = valid ? L.cs[ptr][cand & 15] : 0xffffffffu;
-            uint32_t m = row16_min(tt);  // valid lanes are < 16
             uint32_t pick = start;
-            if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)ballot(valid && tt == m)) - 1;
+            if (start < end) {  // (a single candidate, or none, is its own minimum: about half of the segments of a 100-base read)
+                uint32_t cand = start + lane;
+                bool valid = cand <= end && lane < 16;
+                uint32_t tt = valid ? L.cs[ptr][cand & 15] : 0xffffffffu;
+                uint32_t m = row16_min(tt);  // valid lanes are < 16
+                if (m != 0xffffffffu) pick = start + (uint32_t)__ffsll((unsigned long long)(ballot(tt == m) & ballot(valid))) - 1;
+            }
             if ((uint32_t)lane == ptr) sa = pick;
         }
         if (lane < 16) L.start_arr[c][lane] = (uint8_t)sa;
