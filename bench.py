@@ -4,11 +4,15 @@
 Workload (BASELINE.json config 2): synthetic 100 bp SE reads, -M C:T, -g 0, -S 1, on an
 hg38-sized stand-in genome (tools/synth_gpu.py; hg38 itself is not on the GPU box), reference and
 seed index resident in HBM.  A "step" is ONE call of basal_core_align_batch_device on one batch
-of reads that is already in HBM (descriptors + bases in, 32-byte results out, results stay in HBM).
+of reads that is already in HBM (descriptors + bases in, 32-byte results out, results stay in HBM);
+the default batch is config 2's whole 10 M reads (a launch has a fixed cost of about 1.4 ms -- reads
+from repeats take milliseconds and whichever starts last ends the launch -- so batches of millions
+are how the path is meant to be fed; --batch 1000000 reproduces the 1 M-read launches of DESIGN.md's ladder).
 Timing: W warm-up steps, then K steps between barrier + synchronize, max over ranks;
 value = reads aligned by all ranks / that time.  N > 1 (torchrun): every rank holds the whole
-reference + index, takes its own reads (weak scaling), and the per-read results are gathered to
-rank 0 with ONE RCCL gather inside the timed region.
+reference + index, takes its own reads (weak scaling), and each step's per-read results are gathered
+to rank 0 with one RCCL gather, issued behind the step's kernel so that it overlaps the next step
+(inside the timed region; the last step's gather is exposed).
 
 Extra objects on the JSON line:
   roofline      algorithmic bytes (4H+16S+4C+8W+L+16R per read, counters from the CPU
@@ -39,9 +43,9 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1_000_000, help="reads per step and rank")
+    ap.add_argument("--batch", type=int, default=10_000_000, help="reads per step and rank (default: config 2's 10 M reads as one batch)")
     ap.add_argument("--genome-scale", type=float, default=float(os.environ.get("BASAL_BENCH_SCALE", "1.0")), help="1.0 = hg38-sized (3.09 Gbp)")
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads of the cpu_baseline / parity sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -68,7 +72,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = os.environ.get("BASAL_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
-    if world > 1:
+    # BASAL_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, per-step gather) in a single process -- a rehearsal of
+    # the RCCL calls on a one-GPU box
+    dist_on = world > 1 or bool(os.environ.get("BASAL_BENCH_FORCE_DIST"))
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -117,7 +129,9 @@ def main():
     ms = C.c_uint32()
     assert L.basal_host_filter_read(C.byref(params.c), seq, qual, C.byref(ms)) == 0
     descs = np.zeros(n_reads, bc.READ_DTYPE)
-    descs["seq_off"] = np.arange(n_reads, dtype=np.uint64) * read_len
+    if args.batch * read_len >= 2 ** 32:
+        raise SystemExit("bench: --batch x --read-len must stay below 4 GiB (32-bit byte offsets within one batch)")
+    descs["seq_off"] = (np.arange(n_reads, dtype=np.uint64) % args.batch) * read_len  # relative to the step's own byte buffer
     descs["index"] = np.arange(n_reads, dtype=np.uint32) + rank * n_reads  # global read numbers (myrand)
     descs["len"] = read_len
     descs["max_snp"] = ms.value
@@ -129,14 +143,14 @@ def main():
     core.set_timing(True)
 
     def step(i):
-        rc = L.basal_core_align_batch_device(core.h, d_bases.data_ptr(), d_reads.data_ptr() + i * args.batch * 16, args.batch, None, 0,
+        rc = L.basal_core_align_batch_device(core.h, d_bases.data_ptr() + i * args.batch * read_len, d_reads.data_ptr() + i * args.batch * 16, args.batch, None, 0,
                                              B.STREAM_NONE, d_results.data_ptr() + i * args.batch * 32, None, 0, d_used.data_ptr(), None,
                                              read_len, stream)
         bc._check(rc, "align_batch_device")
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -145,32 +159,53 @@ def main():
     sync_all()
     kernel_ms = []
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty(args.steps * args.batch * 32, dtype=torch.uint8, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    step_bytes = args.batch * 32
+    # rank 0 receives every rank's per-read records, step by step (what it would hand to the SAM writer)
+    gathered = [[torch.empty(step_bytes, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(args.steps)] if (dist_on and rank == 0) else None
+    works = []
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         step(i)
-        kernel_ms.append(core.kernel_ms())  # waits for this step's stop event (HIP events on the launch stream)
+        if not os.environ.get("BASAL_BENCH_NOSYNC"):
+            kernel_ms.append(core.kernel_ms())  # waits for this step's stop event (HIP events on the launch stream)
+        if dist_on:
+            # The one collective of the path: this step's results to the rank that writes SAM. RCCL runs it on its own
+            # stream behind this step's kernel (it orders itself after the work already queued on the current stream), so the
+            # transfer over xGMI overlaps the next step's kernel; only the last step's gather is exposed.
+            sl = d_results[i * step_bytes:(i + 1) * step_bytes]
+            if backend == "nccl":
+                works.append(dist.gather(sl, gathered[i - args.warmup] if rank == 0 else None, dst=0, async_op=True))
+            else:
+                dist.gather(sl.cpu(), gathered[i - args.warmup] if rank == 0 else None, dst=0)
     bc._check(L.basal_core_sync_check(core.h), "align kernels")
-    if world > 1:  # the one collective of the path: per-read results to the rank that writes SAM
-        dist.gather(d_results[args.warmup * args.batch * 32:].to(gdev), gathered, dst=0)
+    for w in works:
+        w.wait()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     reads_timed = args.batch * args.steps * world
-    if world > 1 and rank == 0:  # what rank 0 would hand to the SAM writer: every rank's records, in rank order
-        allres = np.concatenate([np.frombuffer(g.cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE) for g in gathered])
-        assert len(allres) == reads_timed
-        gathered_aligned = int((allres["best_level"] != 0xFF).sum())
+    if dist_on and rank == 0:  # every rank's records arrived: count them (uint8 view of basal_result.best_level, byte 20 of 32)
+        gathered_aligned = 0
+        for per_step in gathered:
+            for g in per_step:
+                gathered_aligned += int((g.view(-1, 32)[:, 20] != 0xFF).sum().item())
+        assert sum(g.numel() for per_step in gathered for g in per_step) == reads_timed * 32
     else:
         gathered_aligned = None
 
-    res = np.frombuffer(d_results.cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE)
-    timed = res[args.warmup * args.batch:]
-    aligned = int((timed["best_level"] != 0xFF).sum())
-    unique = int(((timed["best_level"] != 0xFF) & (timed["n_hit"].astype(np.uint32) + timed["n_chit"] == 1)).sum())
+    # counts over all timed reads on the device (basal_result: n_hit u16 at byte 16, n_chit u16 at 18, best_level u8 at 20);
+    # the first timed step's records come to the host for the oracle sample and the host-buffer cross-check
+    rv = d_results[args.warmup * step_bytes:].view(-1, 32)
+    has = rv[:, 20] != 0xFF
+    nh = rv[:, 16].to(torch.int32) + (rv[:, 17].to(torch.int32) << 8) + rv[:, 18].to(torch.int32) + (rv[:, 19].to(torch.int32) << 8)
+    aligned = int(has.sum().item())
+    unique = int((has & (nh == 1)).sum().item())
+    n_timed = int(rv.shape[0])
+    timed = np.frombuffer(d_results[args.warmup * step_bytes:(args.warmup + 1) * step_bytes].cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE)
+    del rv, has, nh
     blocks_, threads_, lds_ = core.launch_info()
 
     out = {
@@ -181,12 +216,12 @@ def main():
         "config": {"workload": "config 2: %d M synthetic %d bp SE reads per GPU (%d per step), -M %s -g %d -S 1, hg38-sized synthetic genome "
                                "(%.2f Gbp, %d contigs, N gaps, planted repeats), reference + seed index resident in HBM, reads resident in HBM"
                                % (args.batch * args.steps // 1_000_000, args.read_len, args.batch, args.rule, args.gap, total_bp / 1e9, len(sizes)),
-                   "reads_per_step_per_gpu": args.batch, "genome_bp": total_bp, "index_entries": None, "aligned_frac": aligned / max(1, len(timed)),
-                   "unique_frac": unique / max(1, len(timed)), "gathered_aligned_reads": gathered_aligned, "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
+                   "reads_per_step_per_gpu": args.batch, "genome_bp": total_bp, "index_entries": None, "aligned_frac": aligned / max(1, n_timed),
+                   "unique_frac": unique / max(1, n_timed), "gathered_aligned_reads": gathered_aligned, "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
                    "index_build_s": round(t_index, 2)},
     }
 
-    headline = args.rule == "C:T" and args.gap == 0 and args.read_len == 100 and args.genome_scale == 1.0 and args.batch == 1_000_000
+    headline = args.rule == "C:T" and args.gap == 0 and args.read_len == 100 and args.genome_scale == 1.0
     kernel_name = "align_kernel<%d,%s,%s>" % (4 if read_len <= 128 else 8 if read_len <= 256 else 16, "true" if params.c.new_rule else "false",
                                               "true" if args.gap > 0 else "false")
     # ---- cpu_baseline + parity on a bounded sample (rank 0, N=1 only) + roofline ------------------
@@ -194,14 +229,14 @@ def main():
     roof = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle_bridge
-        ns = min(args.cpu_sample, args.batch * args.steps)
+        ns = min(args.cpu_sample, args.batch)  # the head of the first timed step
         ob = oracle_bridge.OracleOnIndex(core, params, flags, G.names, sizes, words)
         out["config"]["index_entries"] = int(len(ob.locs))
         first = args.warmup * args.batch
         sb = d_bases[first * read_len:(first + ns) * read_len].cpu().numpy()
         sd = descs[first:first + ns]
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-        best, cnt, secs_v = ob.align(sb, sd["seq_off"] - first * read_len, sd["len"], sd["index"], sd["max_snp"], threads)
+        best, cnt, secs_v = ob.align(sb, sd["seq_off"], sd["len"], sd["index"], sd["max_snp"], threads)
         bad = oracle_bridge.differing(timed[:ns], best)
         if len(bad):
             raise SystemExit("bench: %d of %d sampled reads differ between the GPU path and the CPU oracle -- number withheld" % (len(bad), ns))
@@ -249,7 +284,7 @@ def main():
     out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
