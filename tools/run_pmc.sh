@@ -29,3 +29,6 @@ done
 cd "$ROOT"
 python3 tools/pmc_summary.py "$OUT" > "gpurun_out/pmc_$TAG.csv"
 cat "gpurun_out/pmc_$TAG.csv"
+# the raw per-dispatch tables (every torch kernel of the workload generator x every counter) are tens of MB: keep the summary
+find "$OUT" -name "*counter_collection.csv" -delete
+find "$OUT" -name "*kernel_trace.csv" -delete

@@ -14,4 +14,5 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT
 cd "$ROOT"
 echo "[profile] kernel-trace bench done: $(cut -c80-140 gpurun_out/${TAG}_bench.json)"
 grep -h "align_kernel\|fill_flanks\|emit_pairs\|split_counts" gpurun_out/prof_$TAG/*/*kernel_stats.csv | cut -c1-60,150-400 || true
+find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete
 bash tools/run_pmc.sh $TAG 2>&1 | grep -v "^    @"
