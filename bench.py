@@ -111,7 +111,10 @@ def main():
 
     # ---- reads resident in HBM -----------------------------------------------------------------
     n_steps = args.steps + args.warmup
-    n_reads = args.batch * n_steps
+    # Every step has its own reads, up to a pool of 8 batches (step i uses batch i % 8): a long run (--steps 100) then
+    # cycles through 80 M distinct reads instead of allocating 150 GB; 1 GB of reads per batch leaves nothing in any cache.
+    n_pool = min(n_steps, 8)
+    n_reads = args.batch * n_pool
     read_len = args.read_len
     frm, to = "ACGT".index(args.rule[0].upper()), "ACGT".index(args.rule[2].upper()) if args.rule[2] in "ACGTacgt" else None
     chunks = []
@@ -143,8 +146,9 @@ def main():
     core.set_timing(True)
 
     def step(i):
-        rc = L.basal_core_align_batch_device(core.h, d_bases.data_ptr() + i * args.batch * read_len, d_reads.data_ptr() + i * args.batch * 16, args.batch, None, 0,
-                                             B.STREAM_NONE, d_results.data_ptr() + i * args.batch * 32, None, 0, d_used.data_ptr(), None,
+        j = i % n_pool
+        rc = L.basal_core_align_batch_device(core.h, d_bases.data_ptr() + j * args.batch * read_len, d_reads.data_ptr() + j * args.batch * 16, args.batch, None, 0,
+                                             B.STREAM_NONE, d_results.data_ptr() + j * args.batch * 32, None, 0, d_used.data_ptr(), None,
                                              read_len, stream)
         bc._check(rc, "align_batch_device")
 
@@ -172,7 +176,7 @@ def main():
             # The one collective of the path: this step's results to the rank that writes SAM. RCCL runs it on its own
             # stream behind this step's kernel (it orders itself after the work already queued on the current stream), so the
             # transfer over xGMI overlaps the next step's kernel; only the last step's gather is exposed.
-            sl = d_results[i * step_bytes:(i + 1) * step_bytes]
+            sl = d_results[(i % n_pool) * step_bytes:((i % n_pool) + 1) * step_bytes]
             if backend == "nccl":
                 works.append(dist.gather(sl, gathered[i - args.warmup] if rank == 0 else None, dst=0, async_op=True))
             else:
@@ -198,13 +202,14 @@ def main():
 
     # counts over all timed reads on the device (basal_result: n_hit u16 at byte 16, n_chit u16 at 18, best_level u8 at 20);
     # the first timed step's records come to the host for the oracle sample and the host-buffer cross-check
-    rv = d_results[args.warmup * step_bytes:].view(-1, 32)
+    first_slot = args.warmup % n_pool  # the first timed step's batch
+    rv = (d_results if n_steps > n_pool else d_results[args.warmup * step_bytes:]).view(-1, 32)
     has = rv[:, 20] != 0xFF
     nh = rv[:, 16].to(torch.int32) + (rv[:, 17].to(torch.int32) << 8) + rv[:, 18].to(torch.int32) + (rv[:, 19].to(torch.int32) << 8)
     aligned = int(has.sum().item())
     unique = int((has & (nh == 1)).sum().item())
     n_timed = int(rv.shape[0])
-    timed = np.frombuffer(d_results[args.warmup * step_bytes:(args.warmup + 1) * step_bytes].cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE)
+    timed = np.frombuffer(d_results[first_slot * step_bytes:(first_slot + 1) * step_bytes].cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE)
     del rv, has, nh
     blocks_, threads_, lds_ = core.launch_info()
 
@@ -232,7 +237,7 @@ def main():
         ns = min(args.cpu_sample, args.batch)  # the head of the first timed step
         ob = oracle_bridge.OracleOnIndex(core, params, flags, G.names, sizes, words)
         out["config"]["index_entries"] = int(len(ob.locs))
-        first = args.warmup * args.batch
+        first = first_slot * args.batch
         sb = d_bases[first * read_len:(first + ns) * read_len].cpu().numpy()
         sd = descs[first:first + ns]
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
