@@ -86,7 +86,7 @@ enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 
 // into d_counter[32..] and printed by basal_core_sync_check. The shipped library compiles these macros away.
 enum { PH_QUEUE = 0, PH_PACK, PH_SEEDS, PH_REORDER, PH_MODE, PH_FILTER, PH_SCORE, PH_REPLAY, PH_FINAL, PH_CHUNK, PH_ENTRY, PH_BYTES, PH_E1, PH_E2, PH_E3, PH_N };
 #ifdef BASAL_PHASE_TIMING
-struct PhaseClock { uint64_t last; uint64_t acc[PH_N]; };
+struct PhaseClock { uint64_t last; uint64_t acc[PH_N]; uint64_t n_chunks, n_alive, n_hits, n_bigchunks, n_bigalive; };
 #define PH_PARAM , PhaseClock &phc
 #define PH_ARG , phc
 #define PH(k) do { uint64_t t_ = __builtin_readcyclecounter(); phc.acc[k] += t_ - phc.last; phc.last = t_; } while (0)
@@ -1148,6 +1148,13 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     alive = lb <= st.thr;
                     PH(PH_FILTER);
                 }
+#ifdef BASAL_PHASE_TIMING
+                {
+                    uint32_t na = (uint32_t)__popcll(ballot(alive));
+                    phc.n_chunks++; phc.n_alive += na;
+                    if (T >= 1024) { phc.n_bigchunks++; phc.n_bigalive += na; }
+                }
+#endif
                 if (alive) {
                     uint32_t off2 = (loc & 31) * 2;
                     uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
@@ -1323,6 +1330,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
 #ifdef BASAL_PHASE_TIMING
     PhaseClock phc;
     for (int i = 0; i < PH_N; i++) phc.acc[i] = 0;
+    phc.n_chunks = phc.n_alive = phc.n_hits = phc.n_bigchunks = phc.n_bigalive = 0;
     phc.last = __builtin_readcyclecounter();
 #endif
     // Work queue: a wave takes WORK_CHUNK consecutive reads per atomic. One atomic per read would cap the
@@ -1376,7 +1384,12 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     }
 #ifdef BASAL_PHASE_TIMING
     if (lane0(lane))
+    {
         for (int i = 0; i < PH_N; i++) atomicAdd((unsigned long long *)(COLDP(unsigned int, guard) + 31) + i, (unsigned long long)phc.acc[i]);
+        unsigned long long *cn = (unsigned long long *)(COLDP(unsigned int, guard) + 31) + PH_N;
+        atomicAdd(cn + 0, (unsigned long long)phc.n_chunks); atomicAdd(cn + 1, (unsigned long long)phc.n_alive);
+        atomicAdd(cn + 2, (unsigned long long)phc.n_bigchunks); atomicAdd(cn + 3, (unsigned long long)phc.n_bigalive);
+    }
 #endif
 }
 
@@ -1424,8 +1437,8 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
     memcpy(tabs + 768, p->alphabet_mread, 256);
     memcpy(tabs + 1024, p->rev_alphabet_mread, 256);
     HIP_TRY(hipMemcpy(c->d_tables, tabs, sizeof tabs, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&c->d_counter, 64 * sizeof(unsigned int)));  // [0] queue head, [1..24] guard ledger, [32..] phase clocks (diagnostic build)
-    HIP_TRY(hipMemset(c->d_counter, 0, 64 * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&c->d_counter, 96 * sizeof(unsigned int)));  // [0] queue head, [1..24] guard ledger, [32..] phase clocks (diagnostic build)
+    HIP_TRY(hipMemset(c->d_counter, 0, 96 * sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&c->d_used, sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -1631,9 +1644,10 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
 #ifdef BASAL_PHASE_TIMING
     {
         static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final", "chunk", "entry", "bytes", "e1", "e2", "e3"};
-        unsigned long long ph[PH_N], tot = 0;
+        unsigned long long ph[PH_N + 4], tot = 0;
         HIP_TRY(hipMemcpy(ph, c->d_counter + 32, sizeof ph, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(c->d_counter + 32, 0, sizeof ph));
+        fprintf(stderr, "[basal counts] chunks %llu alive %llu | in modes with >= 1024 candidates: chunks %llu alive %llu\n", ph[PH_N], ph[PH_N + 1], ph[PH_N + 2], ph[PH_N + 3]);
         for (int i = 0; i < PH_N; i++) tot += ph[i];
         fprintf(stderr, "[basal phases]");
         for (int i = 0; i < PH_N; i++) fprintf(stderr, " %s %.1f%%", nm[i], tot ? 100.0 * ph[i] / tot : 0.0);
