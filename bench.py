@@ -92,7 +92,7 @@ def main():
 
     # ---- reference + index, staged once -----------------------------------------------------
     t0 = time.time()
-    G = synth_gpu.make_genome(params, dev, scale=args.genome_scale, seed=1)
+    G = synth_gpu.make_genome(params, dev, scale=args.genome_scale, seed=1, repeat_copies=int(os.environ.get("BASAL_BENCH_REPEAT_COPIES", "40000")))
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     words = [w.cpu().numpy().view(np.uint64) for w in G.words]
