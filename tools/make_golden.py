@@ -101,6 +101,8 @@ FIXTURES = {
     # a wide index interval: 2I = 24 (chain, phase) seeds per mode (the > 16-entry scan path), few seed segments
     "I12": (["--ref-bp", "300000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--len", "120", "--len-jitter", "30", "--max-sub", "3"],
             ["-M", "C:T", "-S", "1", "-s", "12", "-I", "12", "-n", "1"]),
+    "I3": (["--ref-bp", "300000", "--contigs", "2", "--reads", "300", "-M", "C:T", "--len", "100", "--len-jitter", "20", "--max-sub", "3"],
+           ["-M", "C:T", "-S", "1", "-s", "12", "-I", "3"]),
     "I16_g1": (["--ref-bp", "300000", "--contigs", "2", "--reads", "200", "-M", "A:G", "--p-conv", "0.7", "--len", "150", "--max-sub", "3",
                 "--indel-frac", "0.2", "--indel-max", "1"],
                ["-M", "A:G", "-S", "1", "-s", "12", "-I", "16", "-g", "1"]),
