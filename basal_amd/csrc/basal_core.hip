@@ -1375,6 +1375,8 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
             PH(PH_E3);
 #ifdef BASAL_PHASE_TIMING
             const uint64_t t_read0 = __builtin_readcyclecounter();
+            uint64_t snap[PH_N];
+            for (int i = 0; i < PH_N; i++) snap[i] = phc.acc[i];
 #endif
             process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, r - base, rd, pre, pc, lane PH_ARG);
 #ifdef BASAL_PHASE_TIMING
@@ -1382,6 +1384,8 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
                 const uint64_t dtc = __builtin_readcyclecounter() - t_read0;
                 const int bucket = 63 - __builtin_clzll(dtc | 1);
                 if (lane0(lane)) atomicAdd((unsigned long long *)(COLDP(unsigned int, guard) + 31) + PH_N + 4 + (bucket < 31 ? bucket : 31), 1ull);
+                if (bucket >= 21 && lane0(lane))  // the phase split of the long reads only
+                    for (int i = 0; i < PH_N; i++) atomicAdd((unsigned long long *)(COLDP(unsigned int, guard) + 31) + PH_N + 4 + 32 + i, (unsigned long long)(phc.acc[i] - snap[i]));
             }
 #endif
         }
@@ -1447,8 +1451,8 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
     memcpy(tabs + 768, p->alphabet_mread, 256);
     memcpy(tabs + 1024, p->rev_alphabet_mread, 256);
     HIP_TRY(hipMemcpy(c->d_tables, tabs, sizeof tabs, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&c->d_counter, 192 * sizeof(unsigned int)));  // [0] queue head, [1..24] guard ledger, [32..] phase clocks (diagnostic build)
-    HIP_TRY(hipMemset(c->d_counter, 0, 192 * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&c->d_counter, 256 * sizeof(unsigned int)));  // [0] queue head, [1..24] guard ledger, [32..] phase clocks (diagnostic build)
+    HIP_TRY(hipMemset(c->d_counter, 0, 256 * sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&c->d_used, sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -1654,12 +1658,19 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
 #ifdef BASAL_PHASE_TIMING
     {
         static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final", "chunk", "entry", "bytes", "e1", "e2", "e3"};
-        unsigned long long ph[PH_N + 4 + 32], tot = 0;
+        unsigned long long ph[PH_N + 4 + 32 + PH_N], tot = 0;
         HIP_TRY(hipMemcpy(ph, c->d_counter + 32, sizeof ph, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(c->d_counter + 32, 0, sizeof ph));
         fprintf(stderr, "[basal read-time histogram, log2(wave-clocks): count]");
         for (int b = 0; b < 32; b++) if (ph[PH_N + 4 + b]) fprintf(stderr, " %d:%llu", b, ph[PH_N + 4 + b]);
         fprintf(stderr, "\n");
+        {
+            unsigned long long ht = 0;
+            for (int i = 0; i < PH_N; i++) ht += ph[PH_N + 4 + 32 + i];
+            fprintf(stderr, "[basal phases of reads >= 2^21 clocks]");
+            for (int i = 0; i < PH_N; i++) fprintf(stderr, " %s %.1f%%", nm[i], ht ? 100.0 * ph[PH_N + 4 + 32 + i] / ht : 0.0);
+            fprintf(stderr, "  (total %llu)\n", ht);
+        }
         fprintf(stderr, "[basal counts] chunks %llu alive %llu | in modes with >= 1024 candidates: chunks %llu alive %llu\n", ph[PH_N], ph[PH_N + 1], ph[PH_N + 2], ph[PH_N + 3]);
         for (int i = 0; i < PH_N; i++) tot += ph[i];
         fprintf(stderr, "[basal phases]");
