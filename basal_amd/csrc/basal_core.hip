@@ -1523,7 +1523,7 @@ extern "C" int basal_core_set_index(basal_core_t *c, const uint32_t *kmer_off, c
     c->nlocs = nlocs;
     c->max_kmer_num = max_kmer_num;
     if (!c->have_ref) { g_err = "set_index: stage the reference first (basal_core_set_reference)"; return BASAL_ESTATE; }
-    if (int rc = basal_build_flanks(c)) return rc;
+    if (int rc = basal_build_flanks(c, nullptr)) return rc;
     c->have_index = true;
     return BASAL_OK;
 }
@@ -1711,6 +1711,8 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     HIP_TRY(hipSetDevice(c->device));
     if (stream_used) *stream_used = 0;
     if (n == 0) return BASAL_OK;
+    // basal_read.seq_off is 32 bits: a batch whose bases do not fit would wrap the offsets and align reads against the wrong bytes
+    if (nbases > 0xFFFFFFFFull) { g_err = "align_batch: more than 4 GiB of bases in one batch (basal_read.seq_off is 32-bit); split the batch"; return BASAL_EINVAL; }
     uint32_t max_len = 0;
     const uint32_t K = c->p.seed_size, I = c->p.index_interval;
     for (uint32_t i = 0; i < n; i++) {

@@ -37,4 +37,4 @@ struct basal_core {
     bool timing = false, timed = false;
 };
 
-int basal_build_flanks(basal_core *c);  // basal_index.hip: fills d_flank_a/d_flank_b from the staged reference + index
+int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys);  // basal_index.hip: fills d_flank_a/d_flank_b from the staged reference + index

@@ -98,16 +98,40 @@ __global__ __launch_bounds__(256) void fill_flanks(const uint64_t *__restrict__ 
     }
 }
 
+// The same words, one thread per index ENTRY: right after the GPU build's sort the entry's strand is bit 0 of its sorted key,
+// so no per-k-mer list walk is needed (coalesced location reads and flank stores; lists of 10^4 entries cost what 10^4 short ones do).
+__global__ __launch_bounds__(256) void fill_flanks_sorted(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const uint32_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ locs, unsigned long long nlocs, uint32_t K,
+                                                          uint64_t *__restrict__ fa, uint64_t *__restrict__ fb) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nlocs; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint64_t *x = (keys[i] & 1u) ? xr : xf;
+        const uint32_t g = locs[i];
+        uint32_t p = g + K, a = (p & 31) * 2;
+        const uint64_t *w = x + (p >> 5);
+        fa[i] = a ? (w[0] << a) | (w[1] >> (64 - a)) : w[0];
+        p = g - 32; a = (p & 31) * 2;
+        w = x + (p >> 5);
+        fb[i] = a ? (w[0] << a) | (w[1] >> (64 - a)) : w[0];
+    }
+}
+
 }  // namespace
 
-int basal_build_flanks(basal_core *c) {
+// d_sorted_keys: the GPU build's sorted (2 * kmer + strand) keys, entry for entry with d_locs; nullptr after set_index (host-built arrays)
+int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys) {
     // one allocation, the "before" words right behind the "after" words: the kernel picks one by adding nlocs + 64 to the index
     hipFree(c->d_flank_a);
     c->d_flank_a = c->d_flank_b = nullptr;
     HIP_TRYI(hipMalloc(&c->d_flank_a, 2 * (c->nlocs + 64) * 8));
     c->d_flank_b = c->d_flank_a + (c->nlocs + 64);
-    hipLaunchKernelGGL(fill_flanks, dim3((c->total_kmers + 255) / 256), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], c->d_koff, c->d_knfwd, c->d_locs,
-                       c->total_kmers, c->p.seed_size, c->d_flank_a, c->d_flank_b);
+    if (d_sorted_keys && c->nlocs) {
+        unsigned long long want = (c->nlocs + 255) / 256;
+        uint32_t grid = (uint32_t)std::min<unsigned long long>(want, (unsigned long long)c->prop.multiProcessorCount * 64);
+        hipLaunchKernelGGL(fill_flanks_sorted, dim3(grid), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], d_sorted_keys, c->d_locs, (unsigned long long)c->nlocs,
+                           c->p.seed_size, c->d_flank_a, c->d_flank_b);
+    } else
+        hipLaunchKernelGGL(fill_flanks, dim3((c->total_kmers + 255) / 256), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], c->d_koff, c->d_knfwd, c->d_locs,
+                           c->total_kmers, c->p.seed_size, c->d_flank_a, c->d_flank_b);
     HIP_TRYI(hipGetLastError());
     HIP_TRYI(hipDeviceSynchronize());
     return BASAL_OK;
@@ -167,20 +191,21 @@ extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, u
         TRYC(hipGetLastError());
     }
     size_t tmp_bytes = 0, tmp2 = 0;
-    TRYC(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_off2, (int)nkeys));
+    // item counts go in as size_t: an hg38-sized genome at -I 2 has 3.1 G entries, more than an int holds
+    TRYC(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_off2, nkeys));
     if (npos) {
         int end_bit = 1;
         while ((1ull << end_bit) < nkeys) end_bit++;
-        TRYC(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, d_keys, d_keys2, d_vals, d_vals2, (int)npos, 0, end_bit));
+        TRYC(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, d_keys, d_keys2, d_vals, d_vals2, (size_t)npos, 0, end_bit));
         tmp_bytes = std::max(tmp_bytes, tmp2);
     }
     TRYC(hipMalloc(&d_tmp, tmp_bytes + 256));
-    TRYC(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_off2, (int)nkeys));
+    TRYC(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_off2, nkeys));
     if (npos) {
         int end_bit = 1;
         while ((1ull << end_bit) < nkeys) end_bit++;
         size_t tb = tmp2;
-        TRYC(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (int)npos, 0, end_bit));
+        TRYC(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (size_t)npos, 0, end_bit));
     }
     hipLaunchKernelGGL(split_counts, dim3((total + 1 + 255) / 256), dim3(256), 0, 0, d_off2, d_cnt, total, (uint32_t)npos, c->d_koff, c->d_knfwd);
     TRYC(hipGetLastError());
@@ -210,9 +235,12 @@ extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, u
         }
         c->max_kmer_num = mk;
     }
+    // the flank words, while the sorted keys (strand bit per entry) are still there; the other build buffers go first (HBM head-room)
+    hipFree(d_keys); hipFree(d_vals); hipFree(d_tmp); hipFree(d_cnt); hipFree(d_off2);
+    d_keys = d_vals = d_cnt = d_off2 = nullptr; d_tmp = nullptr;
+    if (int rc = basal_build_flanks(c, d_keys2)) { cleanup(); return rc; }
     cleanup();
 #undef TRYC
-    if (int rc = basal_build_flanks(c)) return rc;
     c->have_index = true;
     if (max_kmer_num_out) *max_kmer_num_out = c->max_kmer_num;
     return BASAL_OK;

@@ -40,6 +40,27 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n):
+    """Run this script as n ranks (one per GPU) under torch.distributed.run; returns the launcher's exit code.
+    On a box with fewer than n GPUs nothing is launched: one JSON line with "skipped" says so and the exit code is 0."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(json.dumps({"metric": "Mreads/s aligned (100 bp SE, -M C:T, hg38) at 1/2/4/8 GPUs; SAM bit-identical", "value": None, "unit": "Mreads/s",
+                          "n_gpus": n, "skipped": "this box has %d GPU(s); %d ranks need one GPU each (set BASAL_DIST_BACKEND=gloo and launch under "
+                                                   "torch.distributed.run to rehearse more ranks than GPUs)" % (have, n)}))
+        return 0
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching %d ranks: %s" % (n, " ".join(cmd)))
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +75,11 @@ def main():
     ap.add_argument("--read-len", type=int, default=100, help="read length (the headline workload is 100; 150/300 exercise the 256/480-base kernels)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` launched plainly: start the N ranks ourselves (children of this process, decided before
+    # anything here has touched a GPU -- device_count() does not initialise HIP), wait, and leave with their exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     import basal_amd as B
@@ -64,8 +90,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
     local = local % torch.cuda.device_count()  # (a gloo rehearsal may put several ranks on one GPU)

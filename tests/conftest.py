@@ -23,10 +23,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Make sure the oracle (checker) and the product library exist; both build without a GPU."""
+    # make is incremental: always run it, so the tests never see artefacts older than the sources. (The GPU box has no
+    # /root/reference and needs none: the prebuilt oracle/_ref/basal travels with the snapshot.)
     import oracle as orc
-    if not (os.path.exists(orc.LIB) and os.path.exists(orc.CLI)):
-        orc.build()
+    orc.build()
     import basal_amd
-    if not (os.path.exists(basal_amd.lib_path()) and os.path.exists(os.path.join(ROOT, "basal_amd", "bin", "basal"))):
-        basal_amd.build()
+    basal_amd.build()
     yield

@@ -18,9 +18,28 @@ SE = sorted(k for k, v in MANIFEST.items() if not v["pe"])
 PE = sorted(k for k, v in MANIFEST.items() if v["pe"])
 
 
+def _generated_fasta(name, g):
+    """A reference too large to commit (tools/gen_contigs.py): regenerated once per checkout into tests/golden/_gen/ and checked
+    against the SHA-256 recorded when the reference binary printed the golden SAM for it."""
+    import hashlib
+    import sys
+    path = os.path.join(GOLD, "_gen", name + ".fa")
+    if not os.path.exists(path):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_contigs as gc
+        fa = gc.fasta_bytes(*gc.make_reference(g["contigs"], g["seed"]))
+        assert hashlib.sha256(fa).hexdigest() == g["sha256"], "regenerated FASTA of %s differs from the one the golden SAM was made on" % name
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path + ".tmp%d" % os.getpid(), "wb") as f:
+            f.write(fa)
+        os.replace(path + ".tmp%d" % os.getpid(), path)
+    return path
+
+
 def fixture_paths(name):
     m = MANIFEST[name]
-    return (os.path.join(GOLD, name + ".fa.gz"), os.path.join(GOLD, m["reads_file"]),
+    fa = _generated_fasta(name, m["fasta_gen"]) if m.get("fasta_gen") else os.path.join(GOLD, name + ".fa.gz")
+    return (fa, os.path.join(GOLD, m["reads_file"]),
             os.path.join(GOLD, name + "_2.fq.gz") if m["pe"] else None, os.path.join(GOLD, name + ".sam.gz"))
 
 

@@ -146,6 +146,15 @@ PE_FIXTURES = {
 }
 
 
+# contig-count edges (tools/gen_contigs.py): 5 000 contigs = three levels of the 64-ary contig search; 140 000 contigs = the
+# reference's 18-bit contig field wraps (param.h:35-42). The 140 000-contig FASTA is regenerated, not committed (sha256 in the manifest).
+CONTIG_FIXTURES = {
+    "contigs_5k": ({"contigs": 5000, "seed": 3, "reads": 150, "len": 100, "rule": "A:G"}, ["-M", "A:G", "-S", "1", "-s", "12", "-n", "1"], True),
+    "contigs_140k": ({"contigs": 140000, "seed": 1, "reads": 120, "len": 100, "rule": "A:G"}, ["-M", "A:G", "-S", "1", "-s", "12", "-n", "1"], False),
+    "contigs_140k_g1": ({"contigs": 140000, "seed": 1, "reads": 120, "len": 100, "rule": "A:G"}, ["-M", "A:G", "-S", "2", "-s", "12", "-g", "1", "-R", "-u"], False),
+}
+
+
 def gz_write(path, data):
     with open(path, "wb") as raw:
         with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, compresslevel=9) as f:
@@ -207,6 +216,30 @@ def main():
                         raise SystemExit("%s: the reference prints a different SAM for the BAM form of the reads" % name)
                     manifest[name]["bam_input_checked"] = True
                 print("%-16s %5d records  flags: %s" % (name, nrec, " ".join(flags)))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hashlib
+    import gen_contigs as gc
+    for name, (g, flags, commit_fa) in CONTIG_FIXTURES.items():
+        if only and name not in only:
+            continue
+        with tempfile.TemporaryDirectory() as td:
+            sizes, starts, seq = gc.make_reference(g["contigs"], g["seed"])
+            fa_b = gc.fasta_bytes(sizes, starts, seq)
+            to = g["rule"][2] if g["rule"][2] in "ACGT" else g["rule"][0]
+            fq_b = gc.fastq_bytes(gc.make_reads(sizes, starts, seq, g["reads"], g["seed"], g["len"], g["rule"][0], to))
+            fa, fq, sam = os.path.join(td, "r.fa"), os.path.join(td, "r.fq"), os.path.join(td, "r.sam")
+            open(fa, "wb").write(fa_b)
+            open(fq, "wb").write(fq_b)
+            run([REF_BIN, "-a", fq, "-d", fa] + flags + ["-p", "1", "-o", sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            body = b"".join(l for l in open(sam, "rb") if not l.startswith(b"@PG"))
+            if commit_fa:
+                gz_write(os.path.join(GOLD, name + ".fa.gz"), fa_b)
+            gz_write(os.path.join(GOLD, name + ".fq.gz"), fq_b)
+            gz_write(os.path.join(GOLD, name + ".sam.gz"), body)
+            nrec = sum(1 for l in body.splitlines() if not l.startswith(b"@"))
+            manifest[name] = {"gen": ["gen_contigs"], "flags": flags, "pe": False, "records": nrec, "reads_file": name + ".fq.gz",
+                              "fasta_gen": None if commit_fa else {"contigs": g["contigs"], "seed": g["seed"], "sha256": hashlib.sha256(fa_b).hexdigest()}}
+            print("%-16s %5d records  flags: %s" % (name, nrec, " ".join(flags)))
     json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
 
 
