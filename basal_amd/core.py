@@ -62,6 +62,25 @@ class basal_mate(C.Structure):
                 ("max_snp", C.c_uint32), ("qc_failed", C.c_int), ("res", C.POINTER(basal_result))]
 
 
+class basal_rawread(C.Structure):
+    _fields_ = [("name_off", C.c_uint32), ("seq_off", C.c_uint32), ("qual_off", C.c_uint32), ("name_len", C.c_uint16),
+                ("seq_len", C.c_uint16), ("qual_len", C.c_uint16), ("readset", C.c_uint8), ("pad", C.c_uint8), ("index", C.c_uint32)]
+
+
+class basal_pipe_opts(C.Structure):
+    _fields_ = [("depth", C.c_uint32), ("max_reads", C.c_uint32), ("max_bytes", C.c_uint64), ("output", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class basal_batch_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_reads", "n_aligned", "n_unique", "n_multiple", "n_filtered")] + [
+        (n, C.c_float) for n in ("ms_h2d", "ms_prep", "ms_align", "ms_format", "ms_d2h")]
+
+
+PIPE_OUT_SAM, PIPE_OUT_RESULTS = 0, 1
+FMT_FASTQ, FMT_FASTA = 0, 1
+RAWREAD_DTYPE = np.dtype([("name_off", "<u4"), ("seq_off", "<u4"), ("qual_off", "<u4"), ("name_len", "<u2"), ("seq_len", "<u2"),
+                          ("qual_len", "<u2"), ("readset", "u1"), ("pad", "u1"), ("index", "<u4")])
+assert RAWREAD_DTYPE.itemsize == 24 and C.sizeof(basal_rawread) == 24
 READ_ALLMODES = 0x80
 HIT_DTYPE = np.dtype([("loc", "<u4"), ("chr", "<u4"), ("gap_size", "i1"), ("strand", "u1"), ("gap_pos", "<u2"),
                       ("level", "u1"), ("chain", "u1"), ("mode", "u1"), ("pad", "u1")])
@@ -93,6 +112,16 @@ SYMBOLS = [
     ("basal_core_last_kernel_ms", C.c_float, [_vp]),
     ("basal_core_launch_info", _i, [_vp, _P(_u32), _P(_u32), _P(_u32)]),
     ("basal_last_error", C.c_char_p, []),
+    ("basal_core_set_contig_names", _i, [_vp, _P(C.c_char_p), _u32]),
+    ("basal_pipe_create", _i, [_vp, _P(basal_pipe_opts), _P(_vp)]),
+    ("basal_pipe_destroy", None, [_vp]),
+    ("basal_pipe_acquire", _i, [_vp, _P(_vp), _P(_vp)]),
+    ("basal_pipe_submit_text", _i, [_vp, _u64, _i, _u32, _u32]),
+    ("basal_pipe_submit_records", _i, [_vp, _u64, _u32]),
+    ("basal_pipe_submit_prepared", _i, [_vp, _u64, _u32, _u32]),
+    ("basal_pipe_collect", _i, [_vp, _P(_vp), _P(_u64), _P(basal_batch_stats)]),
+    ("basal_pipe_release", _i, [_vp]),
+    ("basal_pipe_set_read_range", _i, [_vp, _u32, _u32]),
     ("basal_host_params_defaults", None, [_P(basal_params)]),
     ("basal_host_params_set_seed_size", _i, [_P(basal_params), _i]),
     ("basal_host_params_set_align", _i, [_P(basal_params), C.c_char_p]),
@@ -332,3 +361,75 @@ class Core:
         b, t, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _check(lib().basal_core_launch_info(self.h, C.byref(b), C.byref(t), C.byref(l)), "launch_info")
         return b.value, t.value, l.value
+
+
+    def set_contig_names(self, names):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        _check(lib().basal_core_set_contig_names(self.h, arr, len(names)), "set_contig_names")
+
+
+class Pipe:
+    """basal_pipe_t: batches of raw read text / raw read tables / prepared reads in, SAM text / basal_result records out."""
+
+    def __init__(self, core, depth=3, max_reads=1 << 16, max_bytes=32 << 20, output=PIPE_OUT_SAM):
+        self.core = core
+        self.h = C.c_void_p()
+        self.max_reads = (max_reads + 4095) & ~4095
+        self.max_bytes = (max_bytes + 4095) & ~4095
+        o = basal_pipe_opts(depth, max_reads, max_bytes, output, 0)
+        _check(lib().basal_pipe_create(core.h, C.byref(o), C.byref(self.h)), "pipe_create")
+
+    def close(self):
+        if self.h:
+            lib().basal_pipe_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def acquire(self):
+        """(blob, raw): numpy views of the next slot's page-locked input buffers."""
+        blob, raw = C.c_void_p(), C.c_void_p()
+        _check(lib().basal_pipe_acquire(self.h, C.byref(blob), C.byref(raw)), "pipe_acquire")
+        b = np.ctypeslib.as_array(C.cast(blob, C.POINTER(C.c_uint8)), shape=(self.max_bytes,))
+        r = np.ctypeslib.as_array(C.cast(raw, C.POINTER(C.c_uint8)), shape=(self.max_reads * 24,))
+        return b, r
+
+    def submit_text(self, text, fmt=FMT_FASTQ, first_index=0xFFFFFFFF, readset=0):
+        b, _ = self.acquire()
+        b[: len(text)] = np.frombuffer(text, np.uint8)
+        _check(lib().basal_pipe_submit_text(self.h, len(text), fmt, first_index, readset), "pipe_submit_text")
+
+    def submit_records(self, blob, raw):
+        b, r = self.acquire()
+        b[: len(blob)] = np.frombuffer(blob, np.uint8)
+        rb = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        r[: len(rb)] = rb
+        _check(lib().basal_pipe_submit_records(self.h, len(blob), len(raw)), "pipe_submit_records")
+
+    def submit_prepared(self, bases, descs, max_len):
+        b, r = self.acquire()
+        b[: len(bases)] = bases
+        db = np.ascontiguousarray(descs).view(np.uint8).reshape(-1)
+        r[: len(db)] = db
+        _check(lib().basal_pipe_submit_prepared(self.h, len(bases), len(descs), max_len), "pipe_submit_prepared")
+
+    def collect(self, copy=True):
+        """(rc, bytes, stats): the oldest batch's output. rc != 0 (e.g. BASAL_EIO) is returned, not raised."""
+        out, n, st = C.c_void_p(), C.c_uint64(), basal_batch_stats()
+        rc = lib().basal_pipe_collect(self.h, C.byref(out), C.byref(n), C.byref(st))
+        if rc:
+            return rc, lib().basal_last_error().decode(), st
+        data = C.string_at(out, n.value) if copy else (out.value, n.value)
+        if copy:
+            lib().basal_pipe_release(self.h)
+        return 0, data, st
+
+    def release(self):
+        lib().basal_pipe_release(self.h)
+
+    def set_read_range(self, next_index, read_end=0xFFFFFFFF):
+        _check(lib().basal_pipe_set_read_range(self.h, next_index, read_end), "pipe_set_read_range")

@@ -78,6 +78,13 @@ struct DevCtx {
     uint32_t total_kmers, nlocs;
     unsigned long long nwords, nbases;
     unsigned int *guard;  // [0..7] counts, [8..15] first offending value, [16..23] read number
+    // batch pipeline (basal_pipe.hip): the reads to align as a list of read numbers (one list per read-length class, built on the
+    // device) and its length in device memory, so that a batch whose size only the GPU knows yet can be queued without a host sync;
+    // ghost_base: descriptors [ghost_base, ghost_base + 2) are the reads a stale read of this batch inherits its start offset from
+    // when they lie in an EARLIER batch (their bytes are kept on the device)
+    const uint32_t *order;
+    const uint32_t *n_ptr;
+    uint32_t ghost_base;
 };
 
 enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 5, G_KMER2 = 6, G_WATCHDOG = 7 };
@@ -192,6 +199,7 @@ struct WaveLds {
     };
     SeedEntGap entg[GAP ? 32 : 1];
     SurvEnt surv[GAP ? 128 : 1];  // GAP: the candidates the flank tests could not rule out, in visitation order
+    uint32_t rno[WORK_CHUNK];      // their read numbers (consecutive, or taken from the pipeline's list)
     basal_read desc[WORK_CHUNK];   // the descriptors of the chunk of reads this wave took from the queue
     basal_result res[WORK_CHUNK];  // and their results, written out together when the chunk is done
     uint16_t nhit[2][16];  // x_cur_n_hit[chain][level]
@@ -785,9 +793,12 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
             right = left + stride < right ? left + stride : right;
         }
     uint32_t chr = (left * 2 + strand) & 0x3FFFF;
+    // gHit.chr is an 18-bit field (param.h:35-42): beyond 131 071 contigs it wraps, and int2hit / AddHit read title[gh.chr] -- the
+    // WRAPPED contig's rc_offset and size -- while the anchor subtracted is the true contig's (align.cpp:331-340, align.h:330-331)
+    const uint32_t wc = chr >> 1;
     uint32_t anchor, rcoff = 0, csize;  // separate branches: a select between an LDS and a global pointer would make flat loads
     if (cached) { anchor = s_anchor[left]; csize = s_csize[left]; if (strand) rcoff = s_rcoff[left]; }
-    else { anchor = COLDP(const uint32_t, ref_anchor)[left]; csize = COLDP(const uint32_t, contig_size)[left]; if (strand) rcoff = COLDP(const uint32_t, rc_offset)[left]; }
+    else { anchor = COLDP(const uint32_t, ref_anchor)[left]; csize = COLDP(const uint32_t, contig_size)[wc]; if (strand) rcoff = COLDP(const uint32_t, rc_offset)[wc]; }
     uint32_t l = loc - anchor;
     uint32_t gp = gap_pos & 0x1FF;
     if (strand) {
@@ -943,7 +954,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
     const bool stale = rd.stale_idx < COLD(nstale);
     if (stale) {  // inherit xseed_start_offset from an earlier read of this batch (align.cpp:475-480)
         uint32_t srcno = COLDP(const basal_stale, stales)[rd.stale_idx].src;
-        if (srcno < r) {
+        if (srcno < r || srcno - COLD(ghost_base) < 2u) {
             basal_read src = uniform_read(cx.reads[srcno]);
             rc.rno = r;
             prep_read(cx, L, tab, src, rc, lane, nullptr, -1, 0, 0 PH_ARG);
@@ -1338,6 +1349,10 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     // kernel ran at exactly that ceiling, independent of occupancy, before reads were taken in chunks).
     // Every wave leaves this loop: the queue head only grows, and the iteration bound is a watchdog
     // against an internal error (a wave cannot legitimately take more than n reads).
+    const bool listed = COLD(order) != nullptr;
+    uint32_t n_items = cx.n;
+    if (COLD(n_ptr)) { n_items = *COLDP(const uint32_t, n_ptr); n_items = n_items < cx.n ? n_items : cx.n; }  // cx.n: the capacity of the list
+    if (n_items == 0) return;  // (a read-length class without reads: no queue traffic)
     for (uint32_t iter = 0;; iter++) {
         // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
         if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(ballot(1)), 0, iter); break; }
@@ -1345,20 +1360,25 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)WORK_CHUNK);
         base = rfl(base);
         PH(PH_QUEUE);
-        if (base >= cx.n) break;
-        if (iter > cx.n) { guard_idx(cx, G_WATCHDOG, iter, 0, base); break; }
-        const uint32_t end = base + WORK_CHUNK < cx.n ? base + WORK_CHUNK : cx.n;
+        if (base >= n_items) break;
+        if (iter > n_items) { guard_idx(cx, G_WATCHDOG, iter, 0, base); break; }
+        const uint32_t end = base + WORK_CHUNK < n_items ? base + WORK_CHUNK : n_items;
         // The chunk's descriptors come in with one load, and each read's bytes are requested while the read before it
         // is being aligned, so a read starts on data that is already in registers (2 memory round trips per chunk
         // instead of 2 per read).
-        if ((uint32_t)lane < end - base) L.desc[lane] = cx.reads[base + lane];
+        if ((uint32_t)lane < end - base) {
+            const uint32_t rn = listed ? COLDP(const uint32_t, order)[base + lane] : base + (uint32_t)lane;
+            L.rno[lane] = rn;
+            L.desc[lane] = cx.reads[rn];
+        }
         wave_sync();
         basal_read nrd = uniform_read(L.desc[0]);
         uint32_t npre[NWT / 2];
         int npc = (chain_flags(cx, nrd.readset & 0x7fu) & 1u) ? 0 : 1;
         load_bases<NWT>(cx, nrd, base, npc, lane, npre);
         PH(PH_CHUNK);
-        for (uint32_t r = base; r < end; r++) {
+        for (uint32_t w = base; w < end; w++) {
+            const uint32_t r = listed ? rfl(L.rno[w - base]) : w;  // the read's number in the batch
             if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x30000u | (uint32_t)__popcll(ballot(1)), 0, r); break; }
             const basal_read rd = nrd;
             const int pc = npc;
@@ -1366,11 +1386,11 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
 #pragma unroll
             for (int b = 0; b < NWT / 2; b++) pre[b] = npre[b];
             PH(PH_E1);
-            if (r + 1 < end) {
-                nrd = uniform_read(L.desc[r + 1 - base]);
+            if (w + 1 < end) {
+                nrd = uniform_read(L.desc[w + 1 - base]);
                 npc = (chain_flags(cx, nrd.readset & 0x7fu) & 1u) ? 0 : 1;
                 PH(PH_E2);
-                load_bases<NWT>(cx, nrd, r + 1, npc, lane, npre);
+                load_bases<NWT>(cx, nrd, r, npc, lane, npre);
             }
             PH(PH_E3);
 #ifdef BASAL_PHASE_TIMING
@@ -1378,7 +1398,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
             uint64_t snap[PH_N];
             for (int i = 0; i < PH_N; i++) snap[i] = phc.acc[i];
 #endif
-            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, r - base, rd, pre, pc, lane PH_ARG);
+            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, w - base, rd, pre, pc, lane PH_ARG);
 #ifdef BASAL_PHASE_TIMING
             {   // histogram of per-read wave-clocks by power of two (diagnostic build)
                 const uint64_t dtc = __builtin_readcyclecounter() - t_read0;
@@ -1393,8 +1413,10 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         // previous read's write acknowledgement at its first memory wait)
         wave_sync();
         static_assert(WORK_CHUNK * sizeof(basal_result) == 64 * sizeof(uint32_t), "one dword per lane");
-        if ((uint32_t)lane < (end - base) * (uint32_t)(sizeof(basal_result) / 4))
-            ((uint32_t *)(COLDP(basal_result, results) + base))[lane] = ((const uint32_t *)L.res)[lane];
+        if ((uint32_t)lane < (end - base) * (uint32_t)(sizeof(basal_result) / 4)) {
+            if (!listed) ((uint32_t *)(COLDP(basal_result, results) + base))[lane] = ((const uint32_t *)L.res)[lane];
+            else ((uint32_t *)(COLDP(basal_result, results) + L.rno[lane >> 3]))[lane & 7] = ((const uint32_t *)L.res)[lane];  // still one store instruction per chunk
+        }
     }
 #ifdef BASAL_PHASE_TIMING
     if (lane0(lane))
@@ -1468,6 +1490,7 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipSetDevice(c->device);
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_tables); hipFree(c->d_scratch);
+    hipFree(c->d_names); hipFree(c->d_name_off);
     hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -1593,7 +1616,7 @@ static int report_guard(const unsigned int *guard) {
 // max_len: the longest read of the batch, selects the kernel instantiation
 static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale, uint32_t max_len,
                         int stream_mode, void *d_results,
-                        void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2], hipStream_t s) {
+                        void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2], hipStream_t s, const basal_align_extra *ex = nullptr) {
     if (!c->have_ref || !c->have_index) { g_err = "align: reference/index not staged (call set_reference and set_index/build_index first)"; return BASAL_ESTATE; }
     if (stream_mode < 0 || stream_mode > 2) { g_err = "align: bad stream_mode"; return BASAL_EINVAL; }
     if (stream_mode != BASAL_STREAM_NONE && (!d_stream || !d_stream_used)) { g_err = "align: stream buffers required for this stream_mode"; return BASAL_EINVAL; }
@@ -1614,13 +1637,20 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     cx.results = (basal_result *)d_results; cx.stream = (basal_hit *)d_stream; cx.stream_cap = stream_cap;
     cx.stream_used = (unsigned long long *)d_stream_used;
     cx.scratch = c->d_scratch; cx.scratch_per_wave = c->scratch_per_wave; cx.work_counter = c->d_counter;
+    cx.ghost_base = 0xFFFFFFF0u;  // no descriptor number gets there
+    unsigned int *counter = c->d_counter;
+    if (ex) {  // a pipeline slot: its own queue head, ledger and hit-log scratch (launches of different slots may overlap)
+        cx.order = ex->order; cx.n_ptr = ex->n_ptr; cx.ghost_base = ex->ghost_base;
+        if (ex->counter) { counter = ex->counter; cx.work_counter = counter; }
+        if (ex->scratch) cx.scratch = ex->scratch;
+    }
     memcpy(cx.carry, carry, 4);
     int nwt = max_len <= 128 ? 4 : max_len <= 256 ? 8 : 16;
     c->nwt = nwt;
     bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
     kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp) : nwt == 8 ? pick_kernel<8>(nr, gp) : pick_kernel<16>(nr, gp);
-    HIP_TRY(hipMemsetAsync(c->d_counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
-    cx.guard = c->d_counter + 1;
+    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
+    cx.guard = counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
     const char *env = getenv("BASAL_BLOCKS_PER_CU");
     uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp);
@@ -1630,7 +1660,7 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     c->last_grid = grid;
     uint32_t need = (n + 4 * WORK_CHUNK - 1) / (4 * WORK_CHUNK);
     if (grid > need) grid = need;
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev0, s));
+    if (c->timing && !ex) HIP_TRY(hipEventRecord(c->ev0, s));
     static const bool dbg = getenv("BASAL_DEBUG") != nullptr;
     if (dbg) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -1643,10 +1673,19 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         HIP_TRY(hipStreamSynchronize(s));
         fprintf(stderr, "[basal debug] align kernel finished\n");
     }
-    if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, s)); c->timed = true; }
-    c->last_stream = s;
+    if (c->timing && !ex) { HIP_TRY(hipEventRecord(c->ev1, s)); c->timed = true; }
+    if (!ex) c->last_stream = s;
     return BASAL_OK;
 }
+
+int basal_launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
+                       uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, hipStream_t s,
+                       const basal_align_extra *ex) {
+    static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
+    return launch_align(c, d_bases, nbases_dev, d_reads, n, d_stales, nstale, max_len, stream_mode, d_results, d_stream, stream_cap, d_stream_used, zero_carry, s, ex);
+}
+int basal_ensure_launch_geometry(basal_core *c) { return ensure_launch_geometry(c); }
+int basal_report_guard(const unsigned int *guard) { return report_guard(guard); }
 
 extern "C" int basal_core_sync_check(basal_core_t *c) {
     if (!c) { g_err = "sync_check: null argument"; return BASAL_EINVAL; }

@@ -35,6 +35,24 @@ struct basal_core {
     hipStream_t stream = nullptr, last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, timed = false;
+    // contig names for the device-side SAM writer (basal_core_set_contig_names)
+    char *d_names = nullptr;
+    uint32_t *d_name_off = nullptr;
+    uint32_t n_names = 0;
 };
+
+// what a pipeline slot adds to an align launch (basal_pipe.hip)
+struct basal_align_extra {
+    const uint32_t *order = nullptr;  // device: read numbers to align (nullptr: 0..n-1)
+    const uint32_t *n_ptr = nullptr;  // device: how many of them (nullptr: n)
+    uint32_t ghost_base = 0xFFFFFFF0u;
+    unsigned int *counter = nullptr;  // device: [0] queue head, [1..24] guard ledger of this slot
+    basal_hit *scratch = nullptr;     // device: per-wave hit logs of this slot
+};
+int basal_launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
+                       uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, hipStream_t s,
+                       const basal_align_extra *ex);
+int basal_ensure_launch_geometry(basal_core *c);  // sizes c->grid (largest grid any instantiation uses) and the core's own scratch
+int basal_report_guard(const unsigned int *guard);  // BASAL_OK, or BASAL_EDEVICE + message if the kernel's bounds ledger is not clean
 
 int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys);  // basal_index.hip: fills d_flank_a/d_flank_b from the staged reference + index

@@ -1,0 +1,486 @@
+// basal_pipe.hip -- the batch pipeline around the align kernel: raw read text (or raw read tables, or prepared reads) in
+// page-locked host buffers -> HBM -> device-side parse / FilterReads / inherited-state table (basal_prep.hip) -> align kernels (one
+// launch per read-length class) -> device-side SAM text -> page-locked host buffer.  Every batch slot has its own HIP stream, so the
+// H2D copy of batch k+1 and the D2H copy of batch k-1 overlap the kernels of batch k; the only cross-slot ordering is the small
+// carry state (what later reads inherit from earlier ones), chained through one event per batch.  Nothing is decided on the host
+// from device data until a batch is collected: batch sizes the GPU counted itself (text form) stay on the GPU.
+//
+// Replaces, for the `basal` command line, the reference's per-thread loop LoadBatchReads -> ImportBatchReads -> Do_Batch ->
+// write _str_align (main.cpp:60-92).
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "basal_bits.h"
+#include "basal_internal.h"
+#include "basal_prep.h"
+
+using namespace basal;
+
+namespace {
+
+#define HIP_TRYQ(x)                                                    \
+    do {                                                               \
+        hipError_t e_ = (x);                                           \
+        if (e_ != hipSuccess) {                                        \
+            set_error(std::string(#x) + ": " + hipGetErrorString(e_)); \
+            return BASAL_EDEVICE;                                      \
+        }                                                              \
+    } while (0)
+
+enum { EV_START = 0, EV_H2D, EV_PREP, EV_ALIGN, EV_FORMAT, EV_COUNTERS, EV_OUT, EV_N };
+enum { MODE_TEXT = 0, MODE_RECORDS, MODE_PREPARED };
+enum { ST_FREE = 0, ST_ACQUIRED, ST_INFLIGHT, ST_HELD };
+
+struct Slot {
+    SlotDev d;
+    uint8_t *h_blob = nullptr;
+    basal_rawread *h_raw = nullptr;
+    uint8_t *h_out = nullptr;
+    size_t h_out_cap = 0;
+    BatchCounters *h_cnt = nullptr;
+    unsigned int *h_guard = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[EV_N] = {nullptr};
+    hipEvent_t prep_done = nullptr;
+    int state = ST_FREE;
+    uint32_t batch_no = 0;
+    int mode = MODE_TEXT;
+    uint32_t n_host = 0, max_len = 0;
+    uint64_t nbytes = 0;
+    bool out_queued = false;  // the D2H copy of the output has been queued
+    bool collecting = false;  // basal_pipe_collect is working on this slot (the submitter leaves it alone)
+    uint64_t out_bytes = 0;
+};
+
+}  // namespace
+
+struct basal_pipe {
+    basal_core *c = nullptr;
+    basal_pipe_opts o;
+    PrepConst k;
+    PrepShared sh;
+    std::vector<Slot> slots;
+    std::mutex m;
+    std::condition_variable cv;
+    int acquired = -1, held = -1;
+    std::deque<int> inflight;
+    uint32_t next_batch = 0;
+    hipEvent_t last_prep_done = nullptr;  // of the batch submitted last
+    uint32_t read_end = 0xFFFFFFFFu;
+    char *d_names = nullptr;
+    uint32_t *d_name_off = nullptr;
+};
+
+extern "C" int basal_core_set_contig_names(basal_core_t *c, const char *const *names, uint32_t ncontig) {
+    if (!c || !names || ncontig == 0) { set_error("set_contig_names: bad argument"); return BASAL_EINVAL; }
+    if (c->have_ref && ncontig != c->ncontig) { set_error("set_contig_names: contig count differs from the staged reference"); return BASAL_EINVAL; }
+    HIP_TRYQ(hipSetDevice(c->device));
+    std::string blob;
+    std::vector<uint32_t> off(ncontig + 1);
+    for (uint32_t i = 0; i < ncontig; i++) {
+        off[i] = (uint32_t)blob.size();
+        blob += names[i] ? names[i] : "*";
+    }
+    off[ncontig] = (uint32_t)blob.size();
+    hipFree(c->d_names); hipFree(c->d_name_off);
+    c->d_names = nullptr; c->d_name_off = nullptr;
+    HIP_TRYQ(hipMalloc(&c->d_names, blob.size() + 16));
+    HIP_TRYQ(hipMalloc(&c->d_name_off, (size_t)(ncontig + 1) * 4));
+    HIP_TRYQ(hipMemcpy(c->d_names, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIP_TRYQ(hipMemcpy(c->d_name_off, off.data(), (size_t)(ncontig + 1) * 4, hipMemcpyHostToDevice));
+    c->n_names = ncontig;
+    return BASAL_OK;
+}
+
+static void free_slot(Slot &s) {
+    hipFree(s.d.text); hipFree(s.d.raw); hipFree(s.d.desc); hipFree(s.d.aux); hipFree(s.d.stales); hipFree(s.d.npos); hipFree(s.d.bmax1); hipFree(s.d.bmax2);
+    hipFree(s.d.defidx); hipFree(s.d.order); hipFree(s.d.results); hipFree(s.d.stream); hipFree(s.d.nl); hipFree(s.d.blk_cnt); hipFree(s.d.out_off); hipFree(s.d.out);
+    hipFree(s.d.cnt); hipFree(s.d.counter); hipFree(s.d.scratch); hipFree(s.d.cub_tmp);
+    if (s.h_blob) hipHostFree(s.h_blob);
+    if (s.h_raw) hipHostFree(s.h_raw);
+    if (s.h_out) hipHostFree(s.h_out);
+    if (s.h_cnt) hipHostFree(s.h_cnt);
+    if (s.h_guard) hipHostFree(s.h_guard);
+    for (int i = 0; i < EV_N; i++) if (s.ev[i]) hipEventDestroy(s.ev[i]);
+    if (s.prep_done) hipEventDestroy(s.prep_done);
+    if (s.st) hipStreamDestroy(s.st);
+    s = Slot();
+}
+
+extern "C" void basal_pipe_destroy(basal_pipe_t *p) {
+    if (!p) return;
+    hipSetDevice(p->c->device);
+    hipDeviceSynchronize();
+    for (auto &s : p->slots) free_slot(s);
+    for (uint32_t i = 0; i < p->sh.ncarry; i++) hipFree(p->sh.carry[i]);
+    delete p;
+}
+
+extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basal_pipe_t **out) {
+    if (!c || !out) { set_error("pipe_create: null argument"); return BASAL_EINVAL; }
+    if (!c->have_ref || !c->have_index) { set_error("pipe_create: stage the reference and the index first"); return BASAL_ESTATE; }
+    basal_pipe_opts op;
+    memset(&op, 0, sizeof op);
+    if (o) op = *o;
+    if (op.depth == 0) op.depth = 3;
+    if (op.depth < 2 || op.depth > 8) { set_error("pipe_create: depth must be 2..8"); return BASAL_EINVAL; }
+    if (op.max_reads == 0) op.max_reads = 4u << 20;
+    op.max_reads = (op.max_reads + 4095u) & ~4095u;  // the group maxima of basal_prep.hip work on 4096 reads
+    if (op.max_bytes == 0) op.max_bytes = 512ull << 20;
+    op.max_bytes = (op.max_bytes + 4095ull) & ~4095ull;
+    if (op.max_bytes >= 0xFFFFF000ull) { set_error("pipe_create: max_bytes must stay below 4 GiB (32-bit offsets inside a batch)"); return BASAL_EINVAL; }
+    if (op.output > BASAL_PIPE_OUT_RESULTS) { set_error("pipe_create: bad output mode"); return BASAL_EINVAL; }
+    if (op.output == BASAL_PIPE_OUT_SAM && (!c->d_names || c->n_names != c->ncontig)) { set_error("pipe_create: SAM output needs basal_core_set_contig_names first"); return BASAL_ESTATE; }
+    HIP_TRYQ(hipSetDevice(c->device));
+    int rc = basal_ensure_launch_geometry(c);
+    if (rc) return rc;
+    basal_pipe *p = new basal_pipe();
+    p->c = c;
+    p->o = op;
+    prep_make_const(c->p, p->k);
+    p->sh.names = c->d_names;
+    p->sh.name_off = c->d_name_off;
+    p->sh.ncarry = op.depth + 1;
+    p->slots.resize(op.depth);
+#define TRYD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); basal_pipe_destroy(p); return e_ == hipErrorOutOfMemory ? BASAL_ENOMEM : BASAL_EDEVICE; } } while (0)
+    for (uint32_t i = 0; i < p->sh.ncarry; i++) {
+        TRYD(hipMalloc(&p->sh.carry[i], sizeof(CarryState)));
+        TRYD(hipMemset(p->sh.carry[i], 0, sizeof(CarryState)));
+    }
+    const uint32_t mr = op.max_reads;
+    const size_t cub = prep_cub_tmp_bytes(mr, op.max_bytes);
+    const bool sam = op.output == BASAL_PIPE_OUT_SAM;
+    for (auto &s : p->slots) {
+        SlotDev &d = s.d;
+        d.text_cap = op.max_bytes;
+        TRYD(hipMalloc(&d.text, op.max_bytes + 1024));
+        TRYD(hipMalloc(&d.raw, (size_t)mr * sizeof(basal_rawread)));
+        TRYD(hipMalloc(&d.desc, ((size_t)mr + 2) * sizeof(basal_read)));
+        TRYD(hipMalloc(&d.results, (size_t)mr * sizeof(basal_result)));
+        TRYD(hipMalloc(&d.cnt, sizeof(BatchCounters)));
+        TRYD(hipMalloc(&d.counter, 32 * sizeof(unsigned int)));
+        TRYD(hipMemset(d.counter, 0, 32 * sizeof(unsigned int)));
+        TRYD(hipMalloc(&d.scratch, (size_t)c->grid * 4 * c->scratch_per_wave * sizeof(basal_hit)));
+        if (sam) {
+            TRYD(hipMalloc(&d.aux, (size_t)mr * sizeof(ReadAux)));
+            TRYD(hipMalloc(&d.stales, (size_t)mr * sizeof(basal_stale)));
+            TRYD(hipMalloc(&d.npos, (size_t)6 * mr * sizeof(uint16_t)));
+            TRYD(hipMalloc(&d.bmax1, (size_t)2 * (mr / 64) * sizeof(uint16_t)));
+            TRYD(hipMalloc(&d.bmax2, (size_t)2 * (mr / 4096) * sizeof(uint16_t)));
+            TRYD(hipMalloc(&d.defidx, (size_t)4 * mr * sizeof(int32_t)));
+            TRYD(hipMalloc(&d.order, ((size_t)3 * mr + 2 * kStackMax + 2) * sizeof(uint32_t)));
+            TRYD(hipMalloc(&d.nl, (size_t)4 * mr * sizeof(uint32_t)));
+            TRYD(hipMalloc(&d.blk_cnt, (size_t)(op.max_bytes / 4096 + 2) * sizeof(uint32_t)));
+            TRYD(hipMalloc(&d.out_off, ((size_t)mr + 1) * sizeof(unsigned long long)));
+            d.out_cap = op.max_bytes + op.max_bytes / 2 + (size_t)mr * 64 + 4096;
+            TRYD(hipMalloc(&d.out, d.out_cap));
+            TRYD(hipMalloc(&d.cub_tmp, cub));
+            d.cub_tmp_bytes = cub;
+            if (c->p.report_repeat_hits == 2) {
+                d.stream_cap = (uint64_t)mr * 8 + 4096;
+                TRYD(hipMalloc(&d.stream, d.stream_cap * sizeof(basal_hit)));
+            }
+            s.h_out_cap = d.out_cap;
+        } else s.h_out_cap = (size_t)mr * sizeof(basal_result);
+        TRYD(hipHostMalloc(&s.h_blob, op.max_bytes, hipHostMallocDefault));
+        TRYD(hipHostMalloc(&s.h_raw, (size_t)mr * sizeof(basal_rawread), hipHostMallocDefault));
+        TRYD(hipHostMalloc(&s.h_out, s.h_out_cap, hipHostMallocDefault));
+        TRYD(hipHostMalloc(&s.h_cnt, sizeof(BatchCounters), hipHostMallocDefault));
+        TRYD(hipHostMalloc(&s.h_guard, 24 * sizeof(unsigned int), hipHostMallocDefault));
+        TRYD(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        for (int i = 0; i < EV_N; i++) TRYD(hipEventCreate(&s.ev[i]));
+        TRYD(hipEventCreateWithFlags(&s.prep_done, hipEventDisableTiming));
+    }
+#undef TRYD
+    *out = p;
+    return BASAL_OK;
+}
+
+extern "C" int basal_pipe_acquire(basal_pipe_t *p, uint8_t **blob, basal_rawread **raw) {
+    if (!p) { set_error("pipe_acquire: null argument"); return BASAL_EINVAL; }
+    std::unique_lock<std::mutex> lk(p->m);
+    if (p->acquired >= 0) { set_error("pipe_acquire: the acquired slot has not been submitted"); return BASAL_ESTATE; }
+    for (;;) {
+        for (size_t i = 0; i < p->slots.size(); i++)
+            if (p->slots[i].state == ST_FREE) {
+                p->slots[i].state = ST_ACQUIRED;
+                p->acquired = (int)i;
+                if (blob) *blob = p->slots[i].h_blob;
+                if (raw) *raw = p->slots[i].h_raw;
+                return BASAL_OK;
+            }
+        // every slot is in flight or held by the collector: wait for a collect to release one
+        p->cv.wait(lk);
+    }
+}
+
+// queue the D2H copy of a finished batch's output if its size is known (its counters have arrived) and it fits
+static int try_queue_output(basal_pipe *p, Slot &s, bool wait) {
+    if (s.out_queued) return BASAL_OK;
+    if (wait) HIP_TRYQ(hipEventSynchronize(s.ev[EV_COUNTERS]));
+    else if (hipEventQuery(s.ev[EV_COUNTERS]) != hipSuccess) return BASAL_OK;
+    if (p->o.output == BASAL_PIPE_OUT_SAM) {
+        const BatchCounters &cn = *s.h_cnt;
+        if (cn.irregular || cn.out_bytes > s.d.out_cap) return BASAL_OK;  // collect deals with it
+        if (cn.out_bytes > s.h_out_cap) {
+            if (!wait) return BASAL_OK;
+            hipHostFree(s.h_out);
+            s.h_out = nullptr;
+            s.h_out_cap = cn.out_bytes + cn.out_bytes / 4;
+            HIP_TRYQ(hipHostMalloc(&s.h_out, s.h_out_cap, hipHostMallocDefault));
+        }
+        s.out_bytes = cn.out_bytes;
+        if (s.out_bytes) HIP_TRYQ(hipMemcpyAsync(s.h_out, s.d.out, s.out_bytes, hipMemcpyDeviceToHost, s.st));
+    }
+    HIP_TRYQ(hipEventRecord(s.ev[EV_OUT], s.st));
+    s.out_queued = true;
+    return BASAL_OK;
+}
+
+static int queue_align(basal_pipe *p, Slot &s) {
+    basal_core *c = p->c;
+    SlotDev &d = s.d;
+    const uint32_t mr = p->o.max_reads;
+    const int smode = p->o.output == BASAL_PIPE_OUT_SAM && c->p.report_repeat_hits == 2 ? BASAL_STREAM_BEST : BASAL_STREAM_NONE;
+    if (s.mode == MODE_PREPARED) {
+        basal_align_extra ex;
+        ex.counter = d.counter;
+        ex.scratch = d.scratch;
+        return basal_launch_align(c, d.text, s.nbytes, d.raw, s.n_host, nullptr, 0, s.max_len, BASAL_STREAM_NONE, d.results, nullptr, 0, &d.cnt->stream_used, s.st, &ex);
+    }
+    static const uint32_t cls_len[3] = {128, 256, BASAL_MAXREADLEN};
+    for (int cl = 0; cl < 3; cl++) {
+        if (cls_len[cl] > 128 && c->p.max_readlen <= cls_len[cl - 1]) break;  // -L rules the longer classes out
+        basal_align_extra ex;
+        ex.order = d.order + (size_t)cl * mr;
+        ex.n_ptr = &d.cnt->cls_n[cl];
+        ex.ghost_base = mr;
+        ex.counter = d.counter;
+        ex.scratch = d.scratch;
+        int rc = basal_launch_align(c, d.text, d.text_cap + 1024, d.desc, mr, d.stales, mr, cls_len[cl], smode, d.results, d.stream, d.stream_cap, &d.cnt->stream_used, s.st, &ex);
+        if (rc) return rc;
+    }
+    return BASAL_OK;
+}
+
+static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, int format, uint32_t first_index, uint32_t readset, uint32_t max_len) {
+    if (!p) { set_error("pipe_submit: null argument"); return BASAL_EINVAL; }
+    basal_core *c = p->c;
+    int si;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        si = p->acquired;
+    }
+    if (si < 0) { set_error("pipe_submit: no acquired slot (call basal_pipe_acquire first)"); return BASAL_ESTATE; }
+    Slot &s = p->slots[(size_t)si];
+    auto fail = [&](int rc) {
+        std::lock_guard<std::mutex> lk(p->m);
+        s.state = ST_FREE;
+        p->acquired = -1;
+        p->cv.notify_all();
+        return rc;
+    };
+    if (nbytes > p->o.max_bytes || n > p->o.max_reads) { set_error("pipe_submit: batch larger than the pipe's max_bytes / max_reads"); return fail(BASAL_EINVAL); }
+    if ((mode == MODE_PREPARED) != (p->o.output == BASAL_PIPE_OUT_RESULTS)) { set_error("pipe_submit: prepared reads go with BASAL_PIPE_OUT_RESULTS, text and records with BASAL_PIPE_OUT_SAM"); return fail(BASAL_EINVAL); }
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("pipe_submit: hipSetDevice failed"); return fail(BASAL_EDEVICE); }
+    SlotDev &d = s.d;
+    const uint32_t mr = p->o.max_reads;
+    s.mode = mode; s.nbytes = nbytes; s.n_host = n; s.max_len = max_len; s.out_queued = false; s.out_bytes = 0;
+    uint32_t bno;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        bno = p->next_batch;
+    }
+    s.batch_no = bno;
+#define TRYS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return fail(BASAL_EDEVICE); } } while (0)
+#define TRYR(x) do { int r_ = (x); if (r_) return fail(r_); } while (0)
+    TRYS(hipEventRecord(s.ev[EV_START], s.st));
+    TRYS(hipMemsetAsync(d.cnt, 0, sizeof(BatchCounters), s.st));
+    if (nbytes) TRYS(hipMemcpyAsync(d.text, s.h_blob, nbytes, hipMemcpyHostToDevice, s.st));
+    if (mode == MODE_RECORDS && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_rawread), hipMemcpyHostToDevice, s.st));
+    if (mode == MODE_PREPARED && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s.st));
+    TRYS(hipEventRecord(s.ev[EV_H2D], s.st));
+    if (mode != MODE_PREPARED) {
+        if (p->last_prep_done) TRYS(hipStreamWaitEvent(s.st, p->last_prep_done, 0));  // the carry state of the batch before this one
+        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, p->sh, bno, nbytes, format, first_index, p->read_end, readset, mr, s.st));
+        else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, s.st));
+        TRYR(prep_enqueue_filter(c, p->k, d, p->sh, bno, mr, true, 0, s.st));
+        TRYS(hipEventRecord(s.prep_done, s.st));
+    }
+    TRYS(hipEventRecord(s.ev[EV_PREP], s.st));
+    TRYR(queue_align(p, s));
+    TRYS(hipEventRecord(s.ev[EV_ALIGN], s.st));
+    if (mode != MODE_PREPARED) TRYR(prep_enqueue_format(c, p->k, d, p->sh, mr, s.st));
+    TRYS(hipEventRecord(s.ev[EV_FORMAT], s.st));
+    TRYS(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.st));
+    TRYS(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, s.st));
+    TRYS(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), s.st));
+    if (mode == MODE_PREPARED) {  // the size of the output is known: queue its copy right behind the kernel
+        if (n) TRYS(hipMemcpyAsync(s.h_out, d.results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, s.st));
+        s.out_bytes = (uint64_t)n * sizeof(basal_result);
+        TRYS(hipEventRecord(s.ev[EV_COUNTERS], s.st));
+        TRYS(hipEventRecord(s.ev[EV_OUT], s.st));
+        s.out_queued = true;
+    } else TRYS(hipEventRecord(s.ev[EV_COUNTERS], s.st));
+#undef TRYS
+#undef TRYR
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        if (mode != MODE_PREPARED) p->last_prep_done = s.prep_done;
+        s.state = ST_INFLIGHT;
+        p->inflight.push_back(si);
+        p->acquired = -1;
+        p->next_batch = bno + 1;
+        // the batches in front may have finished meanwhile: start the copy of their output now rather than when they are collected
+        for (int j : p->inflight)
+            if (j != si && !p->slots[(size_t)j].collecting) try_queue_output(p, p->slots[(size_t)j], false);
+    }
+    return BASAL_OK;
+}
+
+extern "C" int basal_pipe_submit_text(basal_pipe_t *p, uint64_t nbytes, int format, uint32_t first_index, uint32_t readset) {
+    if (format != BASAL_FMT_FASTQ && format != BASAL_FMT_FASTA) { set_error("pipe_submit_text: bad format"); return BASAL_EINVAL; }
+    return submit_common(p, MODE_TEXT, nbytes, 0, format, first_index, readset, 0);
+}
+extern "C" int basal_pipe_submit_records(basal_pipe_t *p, uint64_t nblob, uint32_t n) { return submit_common(p, MODE_RECORDS, nblob, n, 0, 0, 0, 0); }
+extern "C" int basal_pipe_submit_prepared(basal_pipe_t *p, uint64_t nbases, uint32_t n, uint32_t max_len) {
+    if (max_len == 0 || max_len > BASAL_MAXREADLEN) { set_error("pipe_submit_prepared: max_len must be 1..480"); return BASAL_EINVAL; }
+    return submit_common(p, MODE_PREPARED, nbases, n, 0, 0, 0, max_len);
+}
+
+extern "C" int basal_pipe_set_read_range(basal_pipe_t *p, uint32_t next_index, uint32_t read_end) {
+    if (!p) { set_error("pipe_set_read_range: null argument"); return BASAL_EINVAL; }
+    std::lock_guard<std::mutex> lk(p->m);
+    if (!p->inflight.empty() || p->acquired >= 0) { set_error("pipe_set_read_range: batches in flight"); return BASAL_ESTATE; }
+    HIP_TRYQ(hipSetDevice(p->c->device));
+    HIP_TRYQ(hipDeviceSynchronize());
+    CarryState *cs = p->sh.carry[p->next_batch % p->sh.ncarry];
+    HIP_TRYQ(hipMemcpy(&cs->next_index, &next_index, sizeof(uint32_t), hipMemcpyHostToDevice));
+    p->read_end = read_end;
+    return BASAL_OK;
+}
+
+extern "C" int basal_pipe_release(basal_pipe_t *p) {
+    if (!p) { set_error("pipe_release: null argument"); return BASAL_EINVAL; }
+    std::lock_guard<std::mutex> lk(p->m);
+    if (p->held >= 0) {
+        p->slots[(size_t)p->held].state = ST_FREE;
+        p->held = -1;
+        p->cv.notify_all();
+    }
+    return BASAL_OK;
+}
+
+extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *nbytes, basal_batch_stats *stats) {
+    if (!p) { set_error("pipe_collect: null argument"); return BASAL_EINVAL; }
+    basal_core *c = p->c;
+    int si;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        if (p->held >= 0) {  // the output handed out last is no longer needed: its slot is free again
+            p->slots[(size_t)p->held].state = ST_FREE;
+            p->held = -1;
+            p->cv.notify_all();
+        }
+        if (p->inflight.empty()) { set_error("pipe_collect: nothing in flight"); return BASAL_ESTATE; }
+        si = p->inflight.front();
+        p->slots[(size_t)si].collecting = true;
+    }
+    Slot &s = p->slots[(size_t)si];
+    HIP_TRYQ(hipSetDevice(c->device));
+    HIP_TRYQ(hipEventSynchronize(s.ev[EV_COUNTERS]));
+    int ret = basal_report_guard(s.h_guard);
+    const bool sam = p->o.output == BASAL_PIPE_OUT_SAM;
+    if (!ret && sam && s.mode == MODE_TEXT && (s.h_cnt->irregular & 1u)) {
+        set_error("pipe: the text of this batch is not regular FASTQ/FASTA (blank lines, white space inside a line, a wrapped sequence, or more reads than max_reads): "
+                  "parse it on the host and submit it with basal_pipe_submit_records");
+        ret = BASAL_EIO;
+    }
+    if (!ret && sam) {
+        // rare second passes, with the batch's inputs still on the device: a hit stream (-r 2) or a text buffer that was too small
+        SlotDev &d = s.d;
+        for (int pass = 0; pass < 4; pass++) {
+            const BatchCounters &cn = *s.h_cnt;
+            const bool stream_small = d.stream && cn.stream_used > d.stream_cap, out_small = cn.out_bytes > d.out_cap;
+            if (!stream_small && !out_small && !(cn.irregular & 2u)) break;
+            HIP_TRYQ(hipStreamSynchronize(s.st));
+            if (stream_small || (cn.irregular & 2u)) {
+                hipFree(d.stream);
+                d.stream = nullptr;
+                d.stream_cap = cn.stream_used + cn.stream_used / 4 + 4096;
+                HIP_TRYQ(hipMalloc(&d.stream, d.stream_cap * sizeof(basal_hit)));
+            }
+            if (out_small) {
+                hipFree(d.out);
+                d.out = nullptr;
+                d.out_cap = cn.out_bytes + cn.out_bytes / 4 + 4096;
+                HIP_TRYQ(hipMalloc(&d.out, d.out_cap));
+            }
+            // counters of the stages that run again
+            BatchCounters z = cn;
+            z.n_aligned = z.n_unique = z.n_multiple = 0; z.out_bytes = 0; z.irregular &= ~2u;
+            if (stream_small || (cn.irregular & 2u)) z.stream_used = 0;
+            HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, s.st));
+            HIP_TRYQ(hipStreamSynchronize(s.st));
+            if (stream_small || (cn.irregular & 2u)) { int rc = queue_align(p, s); if (rc) return rc; }
+            { int rc = prep_enqueue_format(c, p->k, d, p->sh, p->o.max_reads, s.st); if (rc) return rc; }
+            HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.st));
+            HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, s.st));
+            HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), s.st));
+            HIP_TRYQ(hipEventRecord(s.ev[EV_COUNTERS], s.st));
+            HIP_TRYQ(hipEventSynchronize(s.ev[EV_COUNTERS]));
+            if ((ret = basal_report_guard(s.h_guard))) break;
+        }
+    }
+    if (!ret) {
+        int rc = try_queue_output(p, s, true);
+        if (rc) ret = rc;
+        else if (!s.out_queued) { set_error("pipe_collect: output of the batch does not fit after regrowing"); ret = BASAL_EOVERFLOW; }
+        else HIP_TRYQ(hipEventSynchronize(s.ev[EV_OUT]));
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        const BatchCounters &cn = *s.h_cnt;
+        stats->n_reads = s.mode == MODE_PREPARED ? s.n_host : cn.n_reads;
+        stats->n_aligned = cn.n_aligned; stats->n_unique = cn.n_unique; stats->n_multiple = cn.n_multiple; stats->n_filtered = cn.n_filtered;
+        if (!ret) {
+            hipEventElapsedTime(&stats->ms_h2d, s.ev[EV_START], s.ev[EV_H2D]);
+            hipEventElapsedTime(&stats->ms_prep, s.ev[EV_H2D], s.ev[EV_PREP]);
+            hipEventElapsedTime(&stats->ms_align, s.ev[EV_PREP], s.ev[EV_ALIGN]);
+            hipEventElapsedTime(&stats->ms_format, s.ev[EV_ALIGN], s.ev[EV_FORMAT]);
+            hipEventElapsedTime(&stats->ms_d2h, s.ev[EV_COUNTERS], s.ev[EV_OUT]);
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        p->inflight.pop_front();
+        s.collecting = false;
+        if (ret == BASAL_EIO) {
+            // the batches submitted after this one were prepared as if it held no reads: drop them; the caller re-submits from here
+            // (the carry state this batch started from is still in the ring)
+            for (int j : p->inflight) {
+                hipStreamSynchronize(p->slots[(size_t)j].st);
+                p->slots[(size_t)j].state = ST_FREE;
+            }
+            p->inflight.clear();
+            p->next_batch = s.batch_no;
+            p->last_prep_done = nullptr;
+            hipStreamSynchronize(s.st);
+        }
+        if (ret) s.state = ST_FREE;
+        else { s.state = ST_HELD; p->held = si; }
+        // start the output copy of the next finished batch while the caller works on this one
+        if (!p->inflight.empty()) try_queue_output(p, p->slots[(size_t)p->inflight.front()], false);
+        p->cv.notify_all();
+    }
+    if (ret) return ret;
+    if (out) *out = s.h_out;
+    if (nbytes) *nbytes = s.out_bytes;
+    return BASAL_OK;
+}

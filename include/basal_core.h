@@ -186,6 +186,73 @@ int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_t *threads,
 
 const char *basal_last_error(void);
 
+/* ---- device-side read preparation, SAM assembly and the batch pipeline ----
+ * The reference's host does, per 50 000-read batch and single-threaded: parse the input (ReadClass::LoadBatchReads,
+ * reads.cpp:42-110), QC-filter every read (SingleAlign::FilterReads, align.cpp:548-563 with TrimAdapter 418-435,
+ * TrimLowQual 51-76, CountNs 40-47), align, and print SAM (StringAlign/s_OutHit, align.cpp:583-669). basal_pipe_* runs
+ * all of that on the GPU: raw FASTQ/FASTA text (or a table of raw reads over a byte blob) goes in, finished SAM text
+ * comes out, several batches in flight (H2D of batch k+1 and D2H of batch k-1 overlap the kernels of batch k).
+ * State the reference carries from read to read inside one SingleAlign object (basal_stale) is tracked on the device
+ * across batches, so the text equals the reference's `-p 1` output whatever the batch size. */
+
+/* Contig names for the RNAME column (RefSeq::title[].name). names: ncontig NUL-terminated strings. */
+int basal_core_set_contig_names(basal_core_t *c, const char *const *names, uint32_t ncontig);
+
+/* One raw read as the input decoder leaves it (ReadInf, reads.h:17-23; before FilterReads): where its name, bases and
+ * qualities lie in the batch's byte blob. 24 bytes. */
+typedef struct basal_rawread {
+    uint32_t name_off, seq_off, qual_off; /* byte offsets into the blob */
+    uint16_t name_len, seq_len, qual_len; /* qual_len 0 with seq_len > 0: no qualities (FASTA reads) */
+    uint8_t readset, pad;                 /* 0 SE, 1 mate 1, 2 mate 2 */
+    uint32_t index;                       /* ReadInf.index: global read number */
+} basal_rawread;
+
+typedef struct basal_pipe basal_pipe_t;
+typedef struct basal_pipe_opts {
+    uint32_t depth;          /* batches in flight (2..8; 0 = 3) */
+    uint32_t max_reads;      /* reads per batch (0 = 4 Mi) */
+    uint64_t max_bytes;      /* input bytes per batch, < 4 GiB (0 = 512 MiB) */
+    uint32_t output;         /* BASAL_PIPE_OUT_* */
+    uint32_t reserved;
+} basal_pipe_opts;
+#define BASAL_PIPE_OUT_SAM 0     /* SAM text (s_OutHit), reads in input order */
+#define BASAL_PIPE_OUT_RESULTS 1 /* basal_result[n] (+ nothing else): what a multi-GPU gather moves */
+#define BASAL_FMT_FASTQ 0
+#define BASAL_FMT_FASTA 1
+
+typedef struct basal_batch_stats { /* main.cpp:606-612 */
+    uint64_t n_reads, n_aligned, n_unique, n_multiple, n_filtered;
+    float ms_h2d, ms_prep, ms_align, ms_format, ms_d2h; /* HIP-event times of this batch's stages on its stream */
+} basal_batch_stats;
+
+int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basal_pipe_t **out);
+void basal_pipe_destroy(basal_pipe_t *p);
+/* The next free batch slot's page-locked input buffers (blocks while all `depth` slots are in flight and uncollected).
+ * blob: max_bytes bytes; raw: max_reads entries (used by submit_records only; may be ignored). */
+int basal_pipe_acquire(basal_pipe_t *p, uint8_t **blob, basal_rawread **raw);
+/* Submit the acquired slot. text form: `nbytes` of FASTQ (4 lines per record) or FASTA-reads (2 lines per record) text,
+ * whole records only, ending in a newline; the device finds the lines; reads are numbered first_index, first_index+1, ...
+ * (0xFFFFFFFF: continue where the batch before stopped -- only the device has counted its reads) with the given readset.
+ * Returns BASAL_EINVAL-class errors at once; a text the device finds irregular (blank lines, wrapped sequences, white space
+ * inside a sequence line: anything where iostream token parsing and line parsing differ) is reported by collect as BASAL_EIO
+ * for that batch -- re-submit it through submit_records after parsing it on the host. */
+int basal_pipe_submit_text(basal_pipe_t *p, uint64_t nbytes, int format, uint32_t first_index, uint32_t readset);
+int basal_pipe_submit_records(basal_pipe_t *p, uint64_t nblob, uint32_t n);
+/* Already QC-filtered reads (the basal_core_align_batch input) in the acquired slot's blob: bases at blob[0..nbases), the n
+ * descriptors written to (basal_read *)raw by the caller. Output must be BASAL_PIPE_OUT_RESULTS. */
+int basal_pipe_submit_prepared(basal_pipe_t *p, uint64_t nbases, uint32_t n, uint32_t max_len);
+/* Wait for the OLDEST submitted batch. out/nbytes: its output in page-locked host memory (SAM text, or basal_result[n]),
+ * valid until basal_pipe_release or the next collect; stats may be NULL. Returns BASAL_ESTATE when nothing is in flight.
+ * BASAL_EIO: the batch's text is irregular (see submit_text); the batches submitted after it have been dropped and the
+ * pipe continues from this batch: re-submit it (as records) and what followed it.
+ * One thread may acquire/submit while another collects/releases. */
+int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *nbytes, basal_batch_stats *stats);
+/* Done with the output collect handed out: its slot can take a new batch (the next collect does this by itself). */
+int basal_pipe_release(basal_pipe_t *p);
+/* -B / -E (ReadClass::InitIndex, reads.cpp:22-40): the number the next read gets, and the number at which loading stops
+ * (text form: records from read_end on are ignored). Only with nothing in flight. */
+int basal_pipe_set_read_range(basal_pipe_t *p, uint32_t next_index, uint32_t read_end);
+
 /* ---- host helpers ---- */
 void basal_host_params_defaults(basal_params *p);                    /* Param::Param, param.cpp:7-68 */
 int basal_host_params_set_seed_size(basal_params *p, int n);         /* Param::SetSeedSize, param.cpp:108-115 */

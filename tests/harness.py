@@ -121,8 +121,9 @@ def format_se(params, ref, recs, results, stream):
 
 
 def sam_header(ref):
-    buf = C.create_string_buffer(1 << 20)
+    buf = C.create_string_buffer((1 << 20) + 160 * ref.ncontig)
     n = B.lib().basal_host_sam_header(ref.h, b"x", buf, len(buf))
+    assert n >= 0, B.lib().basal_last_error()
     return "".join(l + "\n" for l in buf.raw[:n].decode().splitlines() if not l.startswith("@PG"))
 
 
