@@ -121,6 +121,9 @@ SYMBOLS = [
     ("basal_pipe_submit_prepared", _i, [_vp, _u64, _u32, _u32]),
     ("basal_pipe_collect", _i, [_vp, _P(_vp), _P(_u64), _P(basal_batch_stats)]),
     ("basal_pipe_release", _i, [_vp]),
+    ("basal_pipe_cancel", _i, [_vp]),
+    ("basal_pipe_stop", _i, [_vp]),
+    ("basal_pipe_rewind", _i, [_vp]),
     ("basal_pipe_set_read_range", _i, [_vp, _u32, _u32]),
     ("basal_host_params_defaults", None, [_P(basal_params)]),
     ("basal_host_params_set_seed_size", _i, [_P(basal_params), _i]),
@@ -430,6 +433,9 @@ class Pipe:
 
     def release(self):
         lib().basal_pipe_release(self.h)
+
+    def rewind(self):
+        _check(lib().basal_pipe_rewind(self.h), "pipe_rewind")
 
     def set_read_range(self, next_index, read_end=0xFFFFFFFF):
         _check(lib().basal_pipe_set_read_range(self.h, next_index, read_end), "pipe_set_read_range")

@@ -1,16 +1,24 @@
 // basal_main.cpp -- the `basal` command line on top of libbasal_amd.so.
 //
-// Same flags, messages-to-stderr and SAM-to-file behaviour as the reference driver (main.cpp:272-364
-// option parser, 409-614 RunProcess, 60-92 batch loop), with SingleAlign::Do_Batch replaced by
-// basal_core_align_batch on an MI355X.  Reads are parsed and QC-filtered on the host
-// (reads.cpp:42-83, align.cpp:548-563), aligned on the GPU in large batches, and formatted back
-// to SAM on the host in input order, so the output equals the reference's `-p 1` output.
+// Same flags, messages-to-stderr and SAM-to-file behaviour as the reference driver (main.cpp:272-364 option parser, 409-614
+// RunProcess, 60-92 batch loop).  Single-end runs go through the batch pipeline (basal_pipe_*): a reader thread fills page-locked
+// buffers with raw read text (plain FASTQ / FASTA files: the bytes as they are in the file, the GPU finds the records) or with
+// decoded reads (gzip, BAM, SAM text, irregular text: parsed here with the reference's token semantics, reads.cpp:42-110), the GPU
+// does FilterReads + alignment + SAM text, and the main thread writes the text in input order -- so the output equals the
+// reference's `-p 1` output.  Paired-end runs align both mates on the GPU and pair them on the host (PairAlign, pairs.cpp).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -21,58 +29,104 @@ namespace {
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-struct Reader {  // whole file in memory; iostream-token semantics of ReadClass::LoadBatchReads
-    std::string buf;
-    size_t pos = 0;
-    bool fastq = false;
+void die(const std::string &m, int code = 1) {
+    fprintf(stderr, "%s\n", m.c_str());
+    exit(code);
+}
+
+// ---- streaming input: a sliding window over the (gzip-transparent) byte stream; iostream-token semantics of ReadClass::LoadBatchReads ----
+struct Reader {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;  // window = buf[pos, end)
+    bool eof = false, fastq = false, bam = false, sam = false;
     uint32_t index = 0;
     static bool ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
-    bool open(const char *path) {
-        gzFile f = gzopen(path, "rb");
+    // at least n bytes in the window, or everything up to the end of the stream
+    bool ensure(size_t n) {
+        if (end - pos >= n || eof) return end - pos >= n;
+        if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
+        if (buf.size() < n + (1u << 22)) buf.resize(n + (1u << 22));
+        while (end < buf.size() && !eof) {
+            int got = gzread(f, buf.data() + end, (unsigned)std::min<size_t>(buf.size() - end, 1u << 30));
+            if (got <= 0) eof = true;
+            else end += (size_t)got;
+        }
+        return end - pos >= n;
+    }
+    bool open(const char *path, uint64_t offset = 0) {
+        f = gzopen(path, "rb");
         if (!f) return false;
         gzbuffer(f, 1 << 20);
-        std::vector<char> tmp(1 << 22);
-        int got;
-        while ((got = gzread(f, tmp.data(), (unsigned)tmp.size())) > 0) buf.append(tmp.data(), (size_t)got);
-        gzclose(f);
-        size_t p = 0;
-        while (p < buf.size() && ws((unsigned char)buf[p])) p++;
-        fastq = p < buf.size() && buf[p] == '@';
-        // BAM (main.cpp:386-405 tries FASTA, FASTQ, then BAM): BGZF is multi-member gzip, so buf already holds the
-        // uncompressed stream -- magic, header text, reference table, then the alignment records
-        if (buf.size() >= 12 && memcmp(buf.data(), "BAM\1", 4) == 0) {
+        if (offset) gzseek(f, (z_off_t)offset, SEEK_SET);
+        ensure(1 << 16);
+        size_t p = pos;
+        while (p < end && ws((unsigned char)buf[p])) p++;
+        fastq = p < end && buf[p] == '@';
+        const bool fasta = p < end && buf[p] == '>';
+        // main.cpp:386-405 tries FASTA, FASTQ, then BAM, then SAM text. BGZF is multi-member gzip, so the window already holds
+        // the uncompressed BAM stream: magic, header text, reference table, then the alignment records
+        if (end - pos >= 12 && memcmp(buf.data() + pos, "BAM\1", 4) == 0) {
             bam = true;
             size_t q = 4;
+            ensure(q + 4);
             int32_t l_text = i32(q); q += 4 + (size_t)l_text;
-            if (q + 4 > buf.size()) return false;
+            if (!ensure(q + 4)) return false;
             int32_t n_ref = i32(q); q += 4;
-            for (int32_t k = 0; k < n_ref && q + 4 <= buf.size(); k++) { int32_t l_name = i32(q); q += 4 + (size_t)l_name + 4; }
-            if (q > buf.size()) return false;
-            pos = q;
-        }
+            for (int32_t k = 0; k < n_ref; k++) {
+                if (!ensure(q + 4)) return false;
+                int32_t l_name = i32(q);
+                q += 4 + (size_t)l_name + 4;
+            }
+            if (!ensure(q)) return false;
+            pos += q;
+        } else if (!fastq && !fasta && p < end) sam = true;  // SAM text without a header (one that starts with @HD reads as FASTQ in the reference too)
         return true;
     }
-    bool bam = false;
-    int32_t i32(size_t at) const { int32_t v; memcpy(&v, buf.data() + at, 4); return v; }
-    // next BAM record: [at, at + 4 + block_size); false at the end of the file
-    bool bam_next(size_t &at) {
-        if (pos + 4 > buf.size()) return false;
-        int32_t bs = i32(pos);
-        if (bs < 32 || pos + 4 + (size_t)bs > buf.size()) return false;
-        at = pos + 4;
+    void close() { if (f) gzclose(f); f = nullptr; }
+    int32_t i32(size_t at) const { int32_t v; memcpy(&v, buf.data() + pos + at, 4); return v; }
+    // next BAM record: *at = its offset from pos BEFORE the call advanced pos ... returns pointer to the record body (valid until the next ensure)
+    const unsigned char *bam_next(int32_t &bs) {
+        if (!ensure(4)) return nullptr;
+        bs = i32(0);
+        if (bs < 32 || !ensure(4 + (size_t)bs)) return nullptr;
+        const unsigned char *b = (const unsigned char *)buf.data() + pos + 4;
         pos += 4 + (size_t)bs;
-        return true;
+        return b;
     }
-    void skip_ws() { while (pos < buf.size() && ws((unsigned char)buf[pos])) pos++; }
+    void skip_ws() {
+        for (;;) {
+            while (pos < end && ws((unsigned char)buf[pos])) pos++;
+            if (pos < end || eof) return;
+            ensure(1);
+            if (pos >= end) return;
+        }
+    }
+    // the next white-space delimited token (offsets relative to buf.data(), valid until the next ensure that moves the window)
     void token(size_t &b, size_t &l) {
         skip_ws();
-        b = pos;
-        while (pos < buf.size() && !ws((unsigned char)buf[pos])) pos++;
-        l = pos - b;
+        size_t s = pos;
+        for (;;) {
+            while (pos < end && !ws((unsigned char)buf[pos])) pos++;
+            if (pos < end || eof) break;
+            const size_t rel = pos - s;  // the token runs into the end of the window: pull more in, keep its start
+            pos = s;
+            ensure(rel + (1u << 16));
+            s = pos;
+            pos = s + rel;
+            if (pos >= end) break;
+        }
+        b = s;
+        l = pos - s;
     }
     void rest_of_line() {
-        while (pos < buf.size() && buf[pos] != '\n') pos++;
-        if (pos < buf.size()) pos++;
+        for (;;) {
+            while (pos < end && buf[pos] != '\n') pos++;
+            if (pos < end) { pos++; return; }
+            if (eof) return;
+            ensure(1);
+            if (pos >= end) return;
+        }
     }
 };
 
@@ -82,18 +136,30 @@ struct Rec {
     std::vector<char> seq, qual;  // NUL-terminated, trimmed in place by the filter
     int qc_failed = 0;
     uint32_t max_snp = 0;
+    bool has_qual = true;
 };
 
-// BAM records (reads.cpp:84-110): name, 4-bit bases, phred + 33; with -b the two mates alternate in one file
-// (mate 1 reads a record and skips one, mate 2 skips one and reads), and flags 0x40 / 0x80 name the mate
-int load_batch_bam(Reader &r, const basal_params &p, uint32_t read_end, size_t want, int readset, std::vector<Rec> &out) {
-    static const char nt16[] = "=ACMGRSVTWYHKDBN";
-    out.clear();
-    for (; out.size() < want && r.index < read_end; r.index++) {
-        size_t at, skip;
-        if (readset == 2 && !r.bam_next(skip)) break;
-        if (!r.bam_next(at)) break;
-        const unsigned char *b = (const unsigned char *)r.buf.data() + at;
+const char kNt16[] = "=ACMGRSVTWYHKDBN";
+// what bam_nt16_rev_table[bam_nt16_table[c]] gives (samtools 0.1.18 bam_import.c): the reference reads SAM text through it
+char nt16_roundtrip(char c) {
+    switch (c) {
+        case '=': return '=';
+        case 'A': case 'a': return 'A'; case 'C': case 'c': return 'C'; case 'M': case 'm': return 'M'; case 'G': case 'g': return 'G';
+        case 'R': case 'r': return 'R'; case 'S': case 's': return 'S'; case 'V': case 'v': return 'V'; case 'T': case 't': return 'T';
+        case 'W': case 'w': return 'W'; case 'Y': case 'y': return 'Y'; case 'H': case 'h': return 'H'; case 'K': case 'k': return 'K';
+        case 'D': case 'd': return 'D'; case 'B': case 'b': return 'B';
+        default: return 'N';
+    }
+}
+
+// one read from any input form; false at the end of the input. readset != 0: the BAM/SAM mate conventions of reads.cpp:84-110
+bool next_record(Reader &r, const basal_params &p, int readset, Rec &o) {
+    o.qc_failed = 0; o.max_snp = 0; o.has_qual = true;
+    if (r.bam) {
+        int32_t bs;
+        if (readset == 2 && !r.bam_next(bs)) return false;  // mate 2 skips a record, then reads one
+        const unsigned char *b = r.bam_next(bs);
+        if (!b) return false;
         uint32_t l_name = b[8], n_cigar, flag, l_qseq;
         uint16_t u16;
         memcpy(&u16, b + 12, 2); n_cigar = u16;
@@ -101,62 +167,118 @@ int load_batch_bam(Reader &r, const basal_params &p, uint32_t read_end, size_t w
         memcpy(&l_qseq, b + 16, 4);
         const char *name = (const char *)b + 32;
         const unsigned char *sq = b + 32 + l_name + 4 * n_cigar, *ql = sq + (l_qseq + 1) / 2;
-        if (ql + l_qseq > (const unsigned char *)r.buf.data() + r.pos) break;  // truncated record
+        if (ql + l_qseq > b + bs) return false;  // truncated record
         uint32_t l = std::min<uint32_t>(l_qseq, p.max_readlen);
-        Rec o;
         o.index = r.index;
         o.readset = readset ? ((flag & 0x40) ? 1u : (flag & 0x80) ? 2u : (uint32_t)readset) : 0u;
         o.name.assign(name, strnlen(name, l_name));
         o.seq.assign((size_t)l + 2, 0);
         o.qual.assign((size_t)l + 2, 0);
         for (uint32_t i = 0; i < l; i++) {
-            o.seq[i] = nt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xf];
+            o.seq[i] = kNt16[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xf];
             o.qual[i] = (char)(ql[i] + 33);
         }
-        if (readset == 1 && !r.bam_next(skip)) break;  // (the reference drops a mate 1 without a following record, too)
-        out.push_back(std::move(o));
+        if (readset == 1 && !r.bam_next(bs)) return false;  // (the reference drops a mate 1 without a following record, too)
+        return true;
     }
-    return (int)out.size();
-}
-
-int load_batch(Reader &r, const basal_params &p, uint32_t read_end, size_t want, int readset, std::vector<Rec> &out) {
-    if (r.bam) return load_batch_bam(r, p, read_end, want, readset, out);
-    out.clear();
-    for (; out.size() < want && r.index < read_end; r.index++) {
-        r.skip_ws();
-        if (r.pos >= r.buf.size()) break;
-        r.pos++;
-        size_t nb, nl, sb, sl, qb = 0, ql = 0, tb, tl;
-        r.token(nb, nl);
-        r.rest_of_line();
-        r.token(sb, sl);
-        if (r.fastq) {
-            r.token(tb, tl);
-            r.rest_of_line();
-            r.token(qb, ql);
-        }
-        out.emplace_back();
-        Rec &o = out.back();
+    if (r.sam) {  // one alignment line: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL ...
+        auto line = [&](std::string &out) {
+            out.clear();
+            for (;;) {
+                r.ensure(1);
+                if (r.pos >= r.end) return !out.empty();
+                size_t s = r.pos;
+                while (r.pos < r.end && r.buf[r.pos] != '\n') r.pos++;
+                out.append(r.buf.data() + s, r.pos - s);
+                if (r.pos < r.end) { r.pos++; return true; }
+                if (r.eof) return !out.empty();
+            }
+        };
+        std::string ln, skip;
+        if (readset == 2 && !line(skip)) return false;
+        do { if (!line(ln)) return false; } while (ln.empty() || ln[0] == '@');
+        while (!ln.empty() && (ln.back() == '\r')) ln.pop_back();
+        std::vector<std::pair<size_t, size_t>> fld;
+        size_t s = 0;
+        for (size_t i = 0; i <= ln.size(); i++)
+            if (i == ln.size() || ln[i] == '\t') { fld.push_back({s, i - s}); s = i + 1; }
+        if (fld.size() < 11) return false;
+        const uint32_t flag = (uint32_t)atoi(ln.c_str() + fld[1].first);
+        size_t sl = fld[9].second, ql = fld[10].second;
+        const char *sq = ln.data() + fld[9].first, *qq = ln.data() + fld[10].first;
+        if (sl == 1 && sq[0] == '*') sl = 0;
+        const bool noqual = ql == 1 && qq[0] == '*';
+        uint32_t l = (uint32_t)std::min<size_t>(sl, p.max_readlen);
         o.index = r.index;
-        o.readset = (uint32_t)readset;
-        o.name.assign(r.buf.data() + nb, nl);
-        size_t cap = std::max(sl, ql) + 2;
-        o.seq.assign(cap, 0);
-        o.qual.assign(cap, 0);
-        memcpy(o.seq.data(), r.buf.data() + sb, sl);
-        if (r.fastq) memcpy(o.qual.data(), r.buf.data() + qb, ql);
-        else memset(o.qual.data(), p.zero_qual + p.default_qual, sl);
-        if (sl > p.max_readlen) {
-            o.seq[p.max_readlen] = 0;
-            if (strlen(o.qual.data()) > p.max_readlen) o.qual[p.max_readlen] = 0;
+        o.readset = readset ? ((flag & 0x40) ? 1u : (flag & 0x80) ? 2u : (uint32_t)readset) : 0u;
+        o.name.assign(ln.data() + fld[0].first, fld[0].second);
+        o.seq.assign((size_t)l + 2, 0);
+        o.qual.assign((size_t)l + 2, 0);
+        for (uint32_t i = 0; i < l; i++) {
+            o.seq[i] = nt16_roundtrip(sq[i]);
+            o.qual[i] = noqual ? (char)(0xff + 33) : (char)(((unsigned char)(i < ql ? qq[i] : '!') - 33) + 33);
         }
+        if (readset == 1 && !line(skip)) return false;
+        return true;
+    }
+    r.skip_ws();
+    if (r.pos >= r.end) return false;
+    r.pos++;
+    size_t nb, nl, sb, sl, qb = 0, ql = 0, tb, tl;
+    r.token(nb, nl);
+    o.name.assign(r.buf.data() + nb, nl);
+    r.rest_of_line();
+    r.token(sb, sl);
+    o.seq.assign(sl + 2, 0);
+    memcpy(o.seq.data(), r.buf.data() + sb, sl);
+    if (r.fastq) {
+        r.token(tb, tl);
+        r.rest_of_line();
+        r.token(qb, ql);
+        o.qual.assign(std::max(sl, ql) + 2, 0);
+        memcpy(o.qual.data(), r.buf.data() + qb, ql);
+    } else {
+        o.qual.assign(sl + 2, 0);
+        memset(o.qual.data(), p.zero_qual + p.default_qual, sl);
+        o.has_qual = false;
+    }
+    o.index = r.index;
+    o.readset = (uint32_t)readset;
+    if (sl > p.max_readlen) {  // reads.cpp:63-65
+        o.seq[p.max_readlen] = 0;
+        if (strlen(o.qual.data()) > p.max_readlen) o.qual[p.max_readlen] = 0;
+    }
+    return true;
+}
+
+int load_batch(Reader &r, const basal_params &p, uint32_t read_end, size_t want, int readset, std::vector<Rec> &out, size_t max_bases = ~(size_t)0) {
+    out.clear();
+    size_t bases = 0;
+    for (; out.size() < want && r.index < read_end && bases < max_bases; r.index++) {
+        out.emplace_back();
+        if (!next_record(r, p, readset, out.back())) { out.pop_back(); break; }
+        bases += out.back().seq.size();
     }
     return (int)out.size();
 }
 
-void die(const std::string &m, int code = 1) {
-    fprintf(stderr, "%s\n", m.c_str());
-    exit(code);
+// ReadClass::InitIndex (reads.cpp:13-40): skip the reads before -B
+void skip_reads(Reader &r, const basal_params &p, uint32_t read_start, int pairend) {
+    if (read_start <= 1) { r.index = 0; return; }
+    if (r.bam || r.sam) {
+        Rec tmp;
+        Reader *rp = &r;
+        for (uint32_t i = 0; i < (read_start - 1) * (1u + (uint32_t)pairend); i++)
+            if (!next_record(*rp, p, 0, tmp)) break;
+    } else {
+        const uint32_t maxi = (read_start - 1) * (2 + 2 * (uint32_t)r.fastq);
+        for (uint32_t i = 0; i < maxi; i++) {
+            r.ensure(1);
+            if (r.pos >= r.end) break;
+            r.rest_of_line();
+        }
+    }
+    r.index = read_start - 1;
 }
 
 template <typename F>
@@ -167,17 +289,420 @@ void parallel_for(size_t n, int threads, F f) {
     for (auto &t : th) t.join();
 }
 
+struct Cli {
+    basal_params P;
+    std::string qa, qb, ref_file, out_file, rule, cmdline;
+    int threads = 1, verbose = 1, device = 0, sam_header = 1;
+    uint32_t read_start = 1, read_end = ~0u;
+    size_t batch = 0;
+    bool cpu_index = false;
+};
+
+// ---- output: a FILE* for pipes / stdout, positional parallel writes for regular files ----
+struct Output {
+    FILE *fo = stdout;
+    bool piped = false, regular = false;
+    int fd = -1;
+    uint64_t off = 0;
+    int threads = 1;
+    void write(const char *p, size_t n) {
+        if (!n) return;
+        if (!regular || n < (8u << 20) || threads <= 1) {
+            if (regular) {
+                size_t done = 0;
+                while (done < n) {
+                    ssize_t w = pwrite(fd, p + done, n - done, (off_t)(off + done));
+                    if (w <= 0) die("write failed on the output file");
+                    done += (size_t)w;
+                }
+                off += n;
+            } else if (fwrite(p, 1, n, fo) != n) die("write failed on the output");
+            return;
+        }
+        // a regular file: every thread writes its own range (the page cache takes several GB/s per core, not more)
+        std::vector<std::thread> th;
+        std::atomic<bool> bad{false};
+        for (int t = 0; t < threads; t++)
+            th.emplace_back([&, t] {
+                size_t b = n * (size_t)t / (size_t)threads, e = n * (size_t)(t + 1) / (size_t)threads;
+                while (b < e) {
+                    ssize_t w = pwrite(fd, p + b, std::min<size_t>(e - b, 64u << 20), (off_t)(off + b));
+                    if (w <= 0) { bad = true; return; }
+                    b += (size_t)w;
+                }
+            });
+        for (auto &t : th) t.join();
+        if (bad) die("write failed on the output file");
+        off += n;
+    }
+    void close() {
+        if (piped) pclose(fo);
+        else if (regular) ::close(fd);
+        else if (fo != stdout) fclose(fo);
+        else fflush(stdout);
+    }
+};
+
+// =========================================================================== single-end: the GPU pipeline
+struct SeStats { uint64_t n_reads = 0, n_aligned = 0, n_unique = 0, n_multiple = 0; double ms[5] = {0, 0, 0, 0, 0}; };
+
+// the last complete FASTQ / FASTA record in buf[0, n): returns the number of bytes that hold whole records. A FASTQ record
+// starts at a line that begins with '@' and whose next-but-one line begins with '+' (a quality line may begin with '@', but the
+// line two below it is then a base line, which cannot begin with '+').
+size_t cut_at_record(const char *buf, size_t n, bool fastq, bool at_eof) {
+    if (at_eof) return n;
+    // the starts of the last lines, last first (the last one may be a partial line)
+    size_t starts[24];
+    int ns = 0;
+    size_t p = n;
+    while (ns < 24) {
+        const void *q = p ? memrchr(buf, '\n', p) : nullptr;  // the last newline before byte p
+        const size_t ls = q ? (size_t)((const char *)q - buf) + 1 : 0;
+        if (ls < n) starts[ns++] = ls;
+        if (!q) break;
+        p = (size_t)((const char *)q - buf);
+    }
+    for (int i = 0; i < ns; i++) {
+        const size_t s = starts[i];
+        if (!fastq) { if (buf[s] == '>') return s; continue; }
+        if (buf[s] == '@' && i >= 2 && buf[starts[i - 2]] == '+') return s;
+    }
+    return 0;
+}
+
+void run_se(Cli &cli, basal_core_t *core, Output &out, SeStats &st, double &t_wait_gpu) {
+    const basal_params &P = cli.P;
+    // input form
+    bool plain = false;
+    uint64_t est_bytes = ~0ull;  // an estimate of the uncompressed input size, to size the batches of a small run
+    {
+        FILE *f = fopen(cli.qa.c_str(), "rb");
+        if (!f) die("failed to open read file (check -a option): " + cli.qa);
+        unsigned char m[4] = {0, 0, 0, 0};
+        size_t got = fread(m, 1, 4, f);
+        struct stat sb;
+        const bool reg = fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode), gz = m[0] == 0x1f && m[1] == 0x8b;
+        plain = got >= 1 && !gz && (m[0] == '@' || m[0] == '>') && reg;
+        if (reg) est_bytes = (uint64_t)sb.st_size * (gz ? 8 : 1);
+        fclose(f);
+    }
+    if (getenv("BASAL_HOST_PARSE")) plain = false;
+    basal_pipe_opts po;
+    memset(&po, 0, sizeof po);
+    po.depth = 3;
+    po.max_reads = cli.batch ? (uint32_t)std::min<size_t>(cli.batch, 16u << 20) : (2u << 20);
+    // bytes per batch: room for 100-base FASTQ records with short names at max_reads; longer records make batches of fewer reads
+    po.max_bytes = std::min<uint64_t>((uint64_t)po.max_reads * 160 + (1u << 20), 0xF0000000ull);
+    if (est_bytes < po.max_bytes) {  // a small input: small buffers (page-locking gigabytes takes longer than aligning a few thousand reads)
+        po.max_bytes = std::max<uint64_t>(est_bytes + (64u << 10), 1u << 20);
+        po.max_reads = (uint32_t)std::min<uint64_t>(po.max_reads, std::max<uint64_t>(po.max_bytes / 16, 4096));
+    }
+    if (const char *e = getenv("BASAL_PIPE_BYTES")) po.max_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));  // (tests: many small batches)
+    po.output = BASAL_PIPE_OUT_SAM;
+    basal_pipe_t *pipe = nullptr;
+    if (basal_pipe_create(core, &po, &pipe)) die(std::string("cannot create the pipeline: ") + basal_last_error());
+    po.max_reads = (po.max_reads + 4095u) & ~4095u;
+    po.max_bytes = (po.max_bytes + 4095ull) & ~4095ull;
+    if (basal_pipe_set_read_range(pipe, cli.read_start - 1, cli.read_end)) die(basal_last_error());
+
+    // reader thread -> pipe; the main thread collects and writes. A refused (irregular) text batch restarts the reader in
+    // host-parse mode at the file offset of that batch.
+    struct BatchInfo { uint64_t file_off; };
+    std::mutex qm;
+    std::deque<BatchInfo> submitted;
+    std::atomic<bool> reader_done{false}, stop{false};
+    std::string reader_err;
+    auto reader_text = [&](uint64_t start_off) {
+        int fd = open(cli.qa.c_str(), O_RDONLY);
+        if (fd < 0) { reader_err = "failed to open read file (check -a option): " + cli.qa; reader_done = true; return; }
+        struct stat sb;
+        fstat(fd, &sb);
+        const uint64_t fsize = (uint64_t)sb.st_size;
+        uint64_t off = start_off;
+        bool fastq = true, first = true;
+        // -B: skip the lines of the reads before read_start (text form: on the host, it is a prefix of the file)
+        if (cli.read_start > 1) {
+            Reader r;
+            if (!r.open(cli.qa.c_str())) { reader_err = "failed to open read file"; reader_done = true; ::close(fd); return; }
+            skip_reads(r, P, cli.read_start, 0);
+            off = (uint64_t)gztell(r.f) - (r.end - r.pos);
+            r.close();
+        }
+        std::vector<char> left;
+        const int rthreads = std::max(1, std::min(cli.threads, 8));
+        while (!stop) {
+            uint8_t *blob = nullptr;
+            basal_rawread *raw = nullptr;
+            if (basal_pipe_acquire(pipe, &blob, &raw)) break;  // the pipe was stopped (a batch was refused)
+            if (stop) { basal_pipe_cancel(pipe); break; }
+            size_t have = left.size();
+            memcpy(blob, left.data(), have);
+            const uint64_t batch_off = off - have;
+            const size_t want = (size_t)std::min<uint64_t>(po.max_bytes - 1 - have, fsize - off);
+            if (rthreads > 1 && want > (32u << 20)) {  // the page cache gives a few GB/s per core
+                std::vector<std::thread> th;
+                std::atomic<bool> bad{false};
+                for (int t = 0; t < rthreads; t++)
+                    th.emplace_back([&, t] {
+                        size_t b = want * (size_t)t / (size_t)rthreads, e = want * (size_t)(t + 1) / (size_t)rthreads;
+                        while (b < e) {
+                            ssize_t g = pread(fd, blob + have + b, e - b, (off_t)(off + b));
+                            if (g <= 0) { bad = true; return; }
+                            b += (size_t)g;
+                        }
+                    });
+                for (auto &t : th) t.join();
+                if (bad) { reader_err = "read failed on " + cli.qa; basal_pipe_cancel(pipe); break; }
+            } else {
+                size_t b = 0;
+                while (b < want) {
+                    ssize_t g = pread(fd, blob + have + b, want - b, (off_t)(off + b));
+                    if (g <= 0) break;
+                    b += (size_t)g;
+                }
+                if (b < want) { reader_err = "read failed on " + cli.qa; basal_pipe_cancel(pipe); break; }
+            }
+            off += want;
+            have += want;
+            const bool at_eof = off >= fsize;
+            if (first) {
+                size_t p = 0;
+                while (p < have && Reader::ws(blob[p])) p++;
+                fastq = p < have && blob[p] == '@';
+                first = false;
+            }
+            if (at_eof && have && blob[have - 1] != '\n') blob[have++] = '\n';  // a last line without a newline
+            const size_t keep = cut_at_record((const char *)blob, have, fastq, at_eof);
+            if (keep == 0 && have) {  // no record boundary in a whole buffer: not something the text path can take
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.push_back({batch_off});
+                // hand the whole buffer over: the device flags it irregular and the fallback takes it from there
+                if (basal_pipe_submit_text(pipe, have, fastq ? BASAL_FMT_FASTQ : BASAL_FMT_FASTA, 0xFFFFFFFFu, 0)) break;
+                left.clear();
+                if (at_eof) break;
+                continue;
+            }
+            if (have == 0) { basal_pipe_cancel(pipe); break; }
+            left.assign((const char *)blob + keep, (const char *)blob + have);
+            {
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.push_back({batch_off});
+            }
+            if (basal_pipe_submit_text(pipe, keep, fastq ? BASAL_FMT_FASTQ : BASAL_FMT_FASTA, 0xFFFFFFFFu, 0)) {
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.pop_back();
+                break;
+            }
+            if (at_eof) break;
+        }
+        ::close(fd);
+        reader_done = true;
+    };
+    auto reader_host = [&](uint64_t start_off, uint32_t first_index, bool skip_to_start) {
+        Reader r;
+        if (!r.open(cli.qa.c_str(), start_off)) { reader_err = "failed to open read file (check -a option): " + cli.qa; reader_done = true; return; }
+        if (skip_to_start) skip_reads(r, P, cli.read_start, 0);
+        else r.index = first_index;
+        Rec rec;
+        bool have_rec = false;  // a read that was parsed but did not fit the batch any more: it opens the next one
+        while (!stop) {
+            uint8_t *blob = nullptr;
+            basal_rawread *raw = nullptr;
+            if (basal_pipe_acquire(pipe, &blob, &raw)) break;
+            if (stop) { basal_pipe_cancel(pipe); break; }
+            uint32_t n = 0;
+            uint64_t nb = 0;
+            bool more = true;
+            while (n < po.max_reads && r.index < cli.read_end) {
+                if (!have_rec) {
+                    if (!next_record(r, P, 0, rec)) { more = false; break; }
+                    have_rec = true;
+                }
+                const size_t sl = strlen(rec.seq.data()), ql = rec.has_qual ? strlen(rec.qual.data()) : 0;
+                if (nb + rec.name.size() + sl + ql > po.max_bytes) break;
+                basal_rawread &w = raw[n];
+                memset(&w, 0, sizeof w);
+                w.name_off = (uint32_t)nb; w.name_len = (uint16_t)std::min<size_t>(rec.name.size(), 0xffff);
+                memcpy(blob + nb, rec.name.data(), w.name_len); nb += w.name_len;
+                w.seq_off = (uint32_t)nb; w.seq_len = (uint16_t)sl;
+                memcpy(blob + nb, rec.seq.data(), sl); nb += sl;
+                w.qual_off = (uint32_t)nb; w.qual_len = (uint16_t)ql;
+                memcpy(blob + nb, rec.qual.data(), ql); nb += ql;
+                w.readset = 0; w.index = r.index;
+                n++; r.index++;
+                have_rec = false;
+            }
+            if (n == 0) { basal_pipe_cancel(pipe); break; }
+            {
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.push_back({0});
+            }
+            if (basal_pipe_submit_records(pipe, nb, n)) break;
+            if (!more || r.index >= cli.read_end) break;
+        }
+        r.close();
+        reader_done = true;
+    };
+
+    std::thread rt;
+    if (plain) rt = std::thread(reader_text, (uint64_t)0);
+    else rt = std::thread(reader_host, (uint64_t)0, 0u, true);
+    for (;;) {
+        const void *data = nullptr;
+        uint64_t nbytes = 0;
+        basal_batch_stats bs;
+        double w0 = now();
+        int rc = basal_pipe_collect(pipe, &data, &nbytes, &bs);
+        t_wait_gpu += now() - w0;
+        if (rc == BASAL_ESTATE) {  // nothing in flight
+            if (reader_done) {
+                // the reader may have submitted its last batch between our collect and this test
+                rc = basal_pipe_collect(pipe, &data, &nbytes, &bs);
+                if (rc == BASAL_ESTATE) break;
+            } else { std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }
+        }
+        if (rc == BASAL_EIO && plain) {
+            // irregular text: stop the reader, drop what is in flight, go on in host-parse mode from this batch's first byte
+            stop = true;
+            basal_pipe_stop(pipe);
+            rt.join();
+            uint64_t foff;
+            {
+                std::lock_guard<std::mutex> lk(qm);
+                foff = submitted.empty() ? 0 : submitted.front().file_off;
+                submitted.clear();
+            }
+            if (basal_pipe_rewind(pipe)) die(basal_last_error());
+            if (cli.verbose >= 1) fprintf(stderr, "[BASAL-MI355X] read text is not 4 regular lines per read from byte %llu on: parsing it on the host\n", (unsigned long long)foff);
+            plain = false;
+            stop = false;
+            reader_done = false;
+            rt = std::thread(reader_host, foff, (uint32_t)(cli.read_start - 1 + st.n_reads), false);
+            continue;
+        }
+        if (rc) die(std::string("pipeline: ") + basal_last_error());
+        {
+            std::lock_guard<std::mutex> lk(qm);
+            if (!submitted.empty()) submitted.pop_front();
+        }
+        out.write((const char *)data, (size_t)nbytes);
+        st.n_reads += bs.n_reads; st.n_aligned += bs.n_aligned; st.n_unique += bs.n_unique; st.n_multiple += bs.n_multiple;
+        st.ms[0] += bs.ms_h2d; st.ms[1] += bs.ms_prep; st.ms[2] += bs.ms_align; st.ms[3] += bs.ms_format; st.ms[4] += bs.ms_d2h;
+        if (cli.verbose >= 2) fprintf(stderr, "[BASAL-MI355X] %llu reads finished.\n", (unsigned long long)st.n_reads);
+    }
+    rt.join();
+    if (!reader_err.empty()) die(reader_err);
+    basal_pipe_destroy(pipe);
+}
+
+// =========================================================================== paired-end: GPU alignment, host pairing
+void run_pe(Cli &cli, basal_core_t *core, basal_ref_t *R, Output &out, uint32_t pst[9], uint64_t &n_pairs, double &t_gpu) {
+    basal_params &P = cli.P;
+    const int threads = cli.threads;
+    const size_t batch = cli.batch ? cli.batch : (1u << 20);
+    Reader ra, rb;
+    if (!ra.open(cli.qa.c_str())) die("failed to open read file (check -a option): " + cli.qa);
+    if (!rb.open(cli.qb.c_str())) die("failed to open read file #2 (check -b option): " + cli.qb);
+    skip_reads(ra, P, cli.read_start, 1);
+    skip_reads(rb, P, cli.read_start, 1);
+    // PairAlign::Do_Batch (pairs.cpp:179-202): both mates in one GPU batch (a0,b0,a1,b1,...), pairing on the host
+    std::vector<Rec> ra_, rb_;
+    std::vector<uint8_t> bases;
+    std::vector<basal_read> descs;
+    std::vector<basal_result> results;
+    std::vector<basal_hit> stream;
+    std::vector<basal_stale> stales;
+    basal_stale_tracker_t *tracker = basal_host_stale_new(&P);
+    uint8_t carry[2][2] = {{0, 0}, {0, 0}};
+    for (;;) {
+        // a batch's bases must stay below 4 GiB (32-bit offsets): the base budget closes a batch early
+        int n1 = load_batch(ra, P, cli.read_end, batch / 2 + 1, 1, ra_, (size_t)1800 << 20);
+        int n2 = load_batch(rb, P, cli.read_end, (size_t)n1, 2, rb_);
+        if (!n1 || n1 != n2) break;
+        const size_t np = (size_t)n1;
+        parallel_for(np, threads, [&](size_t b, size_t e, int) {
+            for (size_t i = b; i < e; i++) {
+                ra_[i].qc_failed = basal_host_filter_read(&P, ra_[i].seq.data(), ra_[i].qual.data(), &ra_[i].max_snp);
+                rb_[i].qc_failed = basal_host_filter_read(&P, rb_[i].seq.data(), rb_[i].qual.data(), &rb_[i].max_snp);
+            }
+        });
+        descs.assign(2 * np, basal_read{});
+        bases.clear();
+        stales.clear();
+        basal_host_stale_begin_batch(tracker);
+        for (size_t i = 0; i < np; i++) {
+            std::vector<char> na(ra_[i].name.begin(), ra_[i].name.end()), nb(rb_[i].name.begin(), rb_[i].name.end());
+            na.push_back(0); nb.push_back(0);
+            if (basal_host_fix_pair_names(na.data(), nb.data())) die(basal_last_error());
+            ra_[i].name = na.data(); rb_[i].name = nb.data();
+            const bool both = !ra_[i].qc_failed && !rb_[i].qc_failed;
+            for (int m = 0; m < 2; m++) {
+                Rec &rc_ = m ? rb_[i] : ra_[i];
+                basal_read &d = descs[2 * i + m];
+                d.index = rc_.index;
+                d.readset = (uint8_t)((m ? 2 : 1) | (both ? BASAL_READ_ALLMODES : 0));
+                d.stale_idx = BASAL_STALE_NONE;
+                if (rc_.qc_failed) { d.len = 0; continue; }
+                uint32_t len = (uint32_t)strlen(rc_.seq.data());
+                d.len = (uint16_t)len;
+                d.max_snp = (uint8_t)rc_.max_snp;
+                d.seq_off = (uint32_t)bases.size();
+                bases.insert(bases.end(), rc_.seq.begin(), rc_.seq.begin() + len);
+                basal_stale se;
+                if (basal_host_stale_visit(tracker, rc_.seq.data(), len, m ? 2 : 1, 0, (uint32_t)(2 * i + m), &se)) {
+                    d.stale_idx = (uint32_t)stales.size();
+                    stales.push_back(se);
+                }
+            }
+        }
+        results.assign(2 * np, basal_result{});
+        uint64_t cap = 16 * np + 4096, used = 0;
+        double g0 = now();
+        for (;;) {
+            stream.resize(cap);
+            uint8_t cy[2][2];
+            memcpy(cy, carry, 4);
+            int rc = basal_core_align_batch(core, bases.data(), bases.size(), descs.data(), (uint32_t)(2 * np), stales.data(), (uint32_t)stales.size(),
+                                            BASAL_STREAM_ALL, results.data(), stream.data(), cap, &used, cy);
+            if (rc == BASAL_EOVERFLOW) { cap = used + 4096; continue; }
+            if (rc) die(std::string("align_batch: ") + basal_last_error());
+            memcpy(carry, cy, 4);
+            break;
+        }
+        t_gpu += now() - g0;
+        std::vector<std::string> chunks((size_t)std::max(threads, 1));
+        std::vector<uint32_t> st((size_t)std::max(threads, 1) * 9, 0);
+        parallel_for(np, threads, [&](size_t b, size_t e, int tid) {
+            std::vector<char> line(1 << 16);
+            for (size_t i = b; i < e; i++) {
+                basal_mate ma{ra_[i].name.c_str(), ra_[i].seq.data(), ra_[i].qual.data(), 1, ra_[i].index, ra_[i].max_snp, ra_[i].qc_failed, &results[2 * i]};
+                basal_mate mb{rb_[i].name.c_str(), rb_[i].seq.data(), rb_[i].qual.data(), 2, rb_[i].index, rb_[i].max_snp, rb_[i].qc_failed, &results[2 * i + 1]};
+                size_t need = 8192 + (size_t)(results[2 * i].stream_n + results[2 * i + 1].stream_n + 2 + P.max_num_hits * 2) * (1024 + 2 * (ra_[i].seq.size() + rb_[i].seq.size()));
+                if (line.size() < need) line.resize(need);
+                int64_t w = basal_host_format_pe(&P, R, &ma, &mb, stream.data(), line.data(), line.size(), &st[9 * (size_t)tid]);
+                if (w < 0) die(std::string("format_pe: ") + basal_last_error());
+                chunks[(size_t)tid].append(line.data(), (size_t)w);
+            }
+        });
+        for (auto &c : chunks) out.write(c.data(), c.size());
+        for (size_t t = 0; t < chunks.size(); t++) for (int k = 0; k < 9; k++) pst[k] += st[9 * t + k];
+        n_pairs += np;
+    }
+    basal_host_stale_free(tracker);
+    n_pairs = ra.index - cli.read_start + 1;
+    ra.close();
+    rb.close();
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
-    basal_params P;
+    Cli cli;
+    basal_params &P = cli.P;
     basal_host_params_defaults(&P);
-    std::string qa, qb, ref_file, out_file, rule, cmdline = argv[0];
-    int threads = 1, verbose = 1, device = 0, sam_header = 1;
-    uint32_t read_start = 1, read_end = ~0u;
-    size_t batch = 1u << 20;
-    bool cpu_index = getenv("BASAL_CPU_INDEX") != nullptr;
-    for (int i = 1; i < argc; i++) cmdline += std::string(" ") + argv[i];
+    cli.cmdline = argv[0];
+    cli.cpu_index = getenv("BASAL_CPU_INDEX") != nullptr;
+    for (int i = 1; i < argc; i++) cli.cmdline += std::string(" ") + argv[i];
     if (argc == 1) die("Usage: basal -a reads.fq [-b mates.fq] -d ref.fa -M C:T [options]   (options as in BASAL 1.8.1)");
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -192,18 +717,18 @@ int main(int argc, char **argv) {
         } else if (a[2] == '=') v = a + 3;
         else die(std::string("unknown option: ") + a, i);
         switch (f) {
-            case 'a': qa = v; break;
-            case 'b': qb = v; P.pairend = 1; break;
-            case 'd': ref_file = v; break;
+            case 'a': cli.qa = v; break;
+            case 'b': cli.qb = v; P.pairend = 1; break;
+            case 'd': cli.ref_file = v; break;
             case 's': if (basal_host_params_set_seed_size(&P, atoi(v))) die(basal_last_error()); break;
-            case 'o': out_file = v; break;
-            case 'M': rule = v; break;
+            case 'o': cli.out_file = v; break;
+            case 'M': cli.rule = v; break;
             case 'm': P.min_insert = (uint32_t)atoi(v); break;
             case 'n': P.chains = (uint32_t)atoi(v); break;
             case 'g': P.gap = (uint32_t)atoi(v); if (P.gap > BASAL_MAXGAPS) { fprintf(stderr, "warning: gap length exceeds max value:%d\n", BASAL_MAXGAPS); P.gap = BASAL_MAXGAPS; } break;
             case 'x': P.max_insert = (uint32_t)atoi(v); break;
             case 'r': P.report_repeat_hits = (uint32_t)atoi(v); if (P.report_repeat_hits > 2) die("invalid -r value, must be 0, 1, or 2."); break;
-            case 'V': verbose = atoi(v); break;
+            case 'V': cli.verbose = atoi(v); break;
             case 'I': P.index_interval = (uint32_t)atoi(v); if (P.index_interval > 16 || P.index_interval < 1) die("index interval exceeds max value:16"); break;
             case 'k': P.max_kmer_ratio = (float)atof(v); break;
             case 'v': basal_host_params_set_v(&P, atof(v)); break;
@@ -211,257 +736,103 @@ int main(int argc, char **argv) {
             case 'q': P.trim_qual_threshold = (uint32_t)atoi(v); break;
             case 'f': P.max_ns = (uint32_t)atoi(v); break;
             case 'z': P.zero_qual = (uint8_t)atoi(v); break;
-            case 'p': threads = atoi(v); break;
+            case 'p': cli.threads = atoi(v); break;
             case 'A': if (P.n_adapter < 10) { strncpy(P.adapter[P.n_adapter], v, 127); P.n_adapter++; } break;
             case 'R': P.out_ref = 1; break;
-            case 'H': sam_header = 0; break;
+            case 'H': cli.sam_header = 0; break;
             case 'u': P.out_unmap = 1; break;
-            case 'B': read_start = (uint32_t)std::max(atoi(v), 1); break;
-            case 'E': read_end = (uint32_t)atoi(v); break;
+            case 'B': cli.read_start = (uint32_t)std::max(atoi(v), 1); break;
+            case 'E': cli.read_end = (uint32_t)atoi(v); break;
             case 'L': P.max_readlen = (uint32_t)atoi(v); if (P.max_readlen > BASAL_MAXREADLEN) P.max_readlen = BASAL_MAXREADLEN; break;
             case 'N': P.n_mis = 1; break;
             case 'S': P.randseed = (uint32_t)atoi(v); break;
             case '3': die("-3 (3-nucleotide mode) is not supported by the MI355X build");
             case 'D': die("-D (RRBS digestion sites) is not supported by the MI355X build");
-            case 'G': device = atoi(v); break;  // extension: HIP device ordinal
-            case 'Z': batch = (size_t)atol(v); break;  // extension: reads per GPU batch
+            case 'G': cli.device = atoi(v); break;  // extension: HIP device ordinal
+            case 'Z': cli.batch = (size_t)atol(v); break;  // extension: reads per GPU batch
             case 'h': die("see the BASAL 1.8.1 usage text; this build accepts the same options");
             default: die(std::string("unknown option: ") + a, i);
         }
     }
-    if (rule.empty()) die("\n-M option is required");
-    if (basal_host_params_set_align(&P, rule.c_str())) die(basal_last_error());
-    if (ref_file.empty() || qa.empty()) die("-a and -d are required");
-    if (threads < 1) threads = 1;
-    if (batch < 1) batch = 1;
+    if (cli.rule.empty()) die("\n-M option is required");
+    if (basal_host_params_set_align(&P, cli.rule.c_str())) die(basal_last_error());
+    if (cli.ref_file.empty() || cli.qa.empty()) die("-a and -d are required");
+    if (cli.threads < 1) cli.threads = 1;
 
     double t0 = now();
-    if (verbose >= 1) fprintf(stderr, "[BASAL-MI355X] loading reference file: %s\n", ref_file.c_str());
+    if (cli.verbose >= 1) fprintf(stderr, "[BASAL-MI355X] loading reference file: %s\n", cli.ref_file.c_str());
     basal_ref_t *R = nullptr;
-    if (basal_host_ref_load(&P, ref_file.c_str(), &R)) die(basal_last_error());
+    if (basal_host_ref_load(&P, cli.ref_file.c_str(), &R)) die(basal_last_error());
     double t1 = now();
     basal_core_t *core = nullptr;
-    if (basal_core_create(&P, device, &core)) die(std::string("cannot create the GPU core: ") + basal_last_error());
+    if (basal_core_create(&P, cli.device, &core)) die(std::string("cannot create the GPU core: ") + basal_last_error());
     uint32_t mk = 0;
-    if (cpu_index) {
-        if (basal_host_ref_build_index(R, &P, threads)) die(basal_last_error());
+    if (cli.cpu_index) {
+        if (basal_host_ref_build_index(R, &P, cli.threads)) die(basal_last_error());
         if (basal_host_ref_upload(R, core, 0, &mk)) die(basal_last_error());
     } else if (basal_host_ref_upload(R, core, 1, &mk)) die(basal_last_error());
+    {
+        const uint32_t nc = basal_host_ref_ncontig(R);
+        std::vector<const char *> names(nc);
+        for (uint32_t i = 0; i < nc; i++) names[i] = basal_host_ref_name(R, i);
+        if (basal_core_set_contig_names(core, names.data(), nc)) die(basal_last_error());
+    }
     double t2 = now();
-    if (verbose >= 1)
+    if (cli.verbose >= 1)
         fprintf(stderr, "[BASAL-MI355X] %u reference seqs loaded in %.2f s; seed table (%s) in %.2f s, over-represented k-mer cut-off %u\n",
-                basal_host_ref_ncontig(R), t1 - t0, cpu_index ? "CPU" : "GPU", t2 - t1, mk);
+                basal_host_ref_ncontig(R), t1 - t0, cli.cpu_index ? "CPU" : "GPU", t2 - t1, mk);
 
-    Reader ra, rb;
-    if (!ra.open(qa.c_str())) die("failed to open read file (check -a option): " + qa);
-    if (P.pairend && !rb.open(qb.c_str())) die("failed to open read file #2 (check -b option): " + qb);
-    for (Reader *r : {&ra, &rb}) {  // ReadClass::InitIndex (reads.cpp:13-40)
-        if (r->buf.empty()) continue;
-        uint32_t maxi = (read_start - 1) * (2 + 2 * (uint32_t)r->fastq);
-        for (uint32_t i = 0; i < maxi && r->pos < r->buf.size(); i++) r->rest_of_line();
-        r->index = read_start - 1;
-    }
     // -o x.bam pipes SAM through an external `samtools view -bS -`, like the reference (main.cpp:504-513)
-    bool piped = false;
-    FILE *fo = stdout;
-    if (!out_file.empty()) {
-        if (out_file.size() > 4 && out_file.compare(out_file.size() - 4, 4, ".bam") == 0) {
-            std::string cmd = "samtools view -bS - >" + out_file;
-            fo = popen(cmd.c_str(), "w");
-            piped = fo != nullptr;
-            if (!fo) fprintf(stderr, "unable to creat samtools pipe, writing SAM instead.\n");
+    Output out;
+    out.threads = std::max(1, std::min(cli.threads, 8));
+    if (!cli.out_file.empty()) {
+        if (cli.out_file.size() > 4 && cli.out_file.compare(cli.out_file.size() - 4, 4, ".bam") == 0) {
+            std::string cmd = "samtools view -bS - >" + cli.out_file;
+            out.fo = popen(cmd.c_str(), "w");
+            out.piped = out.fo != nullptr;
+            if (!out.fo) fprintf(stderr, "unable to creat samtools pipe, writing SAM instead.\n");
         }
-        if (!piped) fo = fopen(out_file.c_str(), "w");
+        if (!out.piped) {
+            out.fd = open(cli.out_file.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (out.fd < 0) die("failed to open output file (check -o option): " + cli.out_file);
+            struct stat sb;
+            out.regular = fstat(out.fd, &sb) == 0 && S_ISREG(sb.st_mode);
+            if (!out.regular) { out.fo = fdopen(out.fd, "w"); if (!out.fo) die("failed to open output file (check -o option): " + cli.out_file); }
+        }
     }
-    if (!fo) die("failed to open output file (check -o option): " + out_file);
-    if (sam_header) {
-        std::vector<char> hb(64 + cmdline.size() + 128 * (size_t)basal_host_ref_ncontig(R) + 4096);
-        int64_t n = basal_host_sam_header(R, cmdline.c_str(), hb.data(), hb.size());
+    if (cli.sam_header) {
+        std::vector<char> hb(64 + cli.cmdline.size() + 160 * (size_t)basal_host_ref_ncontig(R) + 4096);
+        int64_t n = basal_host_sam_header(R, cli.cmdline.c_str(), hb.data(), hb.size());
         if (n < 0) die(basal_last_error());
-        fwrite(hb.data(), 1, (size_t)n, fo);
+        out.write(hb.data(), (size_t)n);
     }
 
-    uint64_t n_total = 0, n_aligned = 0, n_unique = 0, n_multiple = 0;
-    double t_gpu = 0, t_host = 0, t3 = now();
-    uint8_t carry[2][2] = {{0, 0}, {0, 0}};
+    double t3 = now();
     if (P.pairend) {
-        // PairAlign::Do_Batch (pairs.cpp:179-202): both mates in one GPU batch (a0,b0,a1,b1,...), pairing on the host
-        std::vector<Rec> ra_, rb_;
-        std::vector<uint8_t> bases;
-        std::vector<basal_read> descs;
-        std::vector<basal_result> results;
-        std::vector<basal_hit> stream;
-        std::vector<basal_stale> stales;
-        basal_stale_tracker_t *tracker = basal_host_stale_new(&P);
         uint32_t pst[9] = {0};
-        for (;;) {
-            int n1 = load_batch(ra, P, read_end, batch / 2 + 1, 1, ra_);
-            int n2 = load_batch(rb, P, read_end, batch / 2 + 1, 2, rb_);
-            if (!n1 || n1 != n2) break;
-            const size_t np = (size_t)n1;
-            parallel_for(np, threads, [&](size_t b, size_t e, int) {
-                for (size_t i = b; i < e; i++) {
-                    ra_[i].qc_failed = basal_host_filter_read(&P, ra_[i].seq.data(), ra_[i].qual.data(), &ra_[i].max_snp);
-                    rb_[i].qc_failed = basal_host_filter_read(&P, rb_[i].seq.data(), rb_[i].qual.data(), &rb_[i].max_snp);
-                }
-            });
-            descs.assign(2 * np, basal_read{});
-            bases.clear();
-            stales.clear();
-            basal_host_stale_begin_batch(tracker);
-            for (size_t i = 0; i < np; i++) {
-                std::vector<char> na(ra_[i].name.begin(), ra_[i].name.end()), nb(rb_[i].name.begin(), rb_[i].name.end());
-                na.push_back(0); nb.push_back(0);
-                if (basal_host_fix_pair_names(na.data(), nb.data())) die(basal_last_error());
-                ra_[i].name = na.data(); rb_[i].name = nb.data();
-                const bool both = !ra_[i].qc_failed && !rb_[i].qc_failed;
-                for (int m = 0; m < 2; m++) {
-                    Rec &rc_ = m ? rb_[i] : ra_[i];
-                    basal_read &d = descs[2 * i + m];
-                    d.index = rc_.index;
-                    d.readset = (uint8_t)((m ? 2 : 1) | (both ? BASAL_READ_ALLMODES : 0));
-                    d.stale_idx = BASAL_STALE_NONE;
-                    if (rc_.qc_failed) { d.len = 0; continue; }
-                    uint32_t len = (uint32_t)strlen(rc_.seq.data());
-                    d.len = (uint16_t)len;
-                    d.max_snp = (uint8_t)rc_.max_snp;
-                    d.seq_off = (uint32_t)bases.size();
-                    bases.insert(bases.end(), rc_.seq.begin(), rc_.seq.begin() + len);
-                    basal_stale se;
-                    if (basal_host_stale_visit(tracker, rc_.seq.data(), len, m ? 2 : 1, 0, (uint32_t)(2 * i + m), &se)) {
-                        d.stale_idx = (uint32_t)stales.size();
-                        stales.push_back(se);
-                    }
-                }
-            }
-            results.assign(2 * np, basal_result{});
-            uint64_t cap = 16 * np + 4096, used = 0;
-            double g0 = now();
-            for (;;) {
-                stream.resize(cap);
-                uint8_t cy[2][2];
-                memcpy(cy, carry, 4);
-                int rc = basal_core_align_batch(core, bases.data(), bases.size(), descs.data(), (uint32_t)(2 * np), stales.data(), (uint32_t)stales.size(),
-                                                BASAL_STREAM_ALL, results.data(), stream.data(), cap, &used, cy);
-                if (rc == BASAL_EOVERFLOW) { cap = used + 4096; continue; }
-                if (rc) die(std::string("align_batch: ") + basal_last_error());
-                memcpy(carry, cy, 4);
-                break;
-            }
-            t_gpu += now() - g0;
-            std::vector<std::string> chunks((size_t)std::max(threads, 1));
-            std::vector<uint32_t> st((size_t)std::max(threads, 1) * 9, 0);
-            parallel_for(np, threads, [&](size_t b, size_t e, int tid) {
-                std::vector<char> line(1 << 16);
-                for (size_t i = b; i < e; i++) {
-                    basal_mate ma{ra_[i].name.c_str(), ra_[i].seq.data(), ra_[i].qual.data(), 1, ra_[i].index, ra_[i].max_snp, ra_[i].qc_failed, &results[2 * i]};
-                    basal_mate mb{rb_[i].name.c_str(), rb_[i].seq.data(), rb_[i].qual.data(), 2, rb_[i].index, rb_[i].max_snp, rb_[i].qc_failed, &results[2 * i + 1]};
-                    size_t need = 8192 + (size_t)(results[2 * i].stream_n + results[2 * i + 1].stream_n + 2 + P.max_num_hits * 2) * (1024 + 2 * (ra_[i].seq.size() + rb_[i].seq.size()));
-                    if (line.size() < need) line.resize(need);
-                    int64_t w = basal_host_format_pe(&P, R, &ma, &mb, stream.data(), line.data(), line.size(), &st[9 * (size_t)tid]);
-                    if (w < 0) die(std::string("format_pe: ") + basal_last_error());
-                    chunks[(size_t)tid].append(line.data(), (size_t)w);
-                }
-            });
-            for (auto &c : chunks) fwrite(c.data(), 1, c.size(), fo);
-            for (size_t t = 0; t < chunks.size(); t++) for (int k = 0; k < 9; k++) pst[k] += st[9 * t + k];
-            n_total += np;
-        }
-        if (verbose >= 1) {
-            uint32_t tot = ra.index - read_start + 1;
-            fprintf(stderr, "[BASAL-MI355X] total read pairs: %u \ttotal time:  %.2f secs (GPU batches %.3f s)\n", tot, now() - t0, t_gpu);
+        uint64_t n_pairs = 0;
+        double t_gpu = 0;
+        run_pe(cli, core, R, out, pst, n_pairs, t_gpu);
+        out.close();
+        if (cli.verbose >= 1) {
+            fprintf(stderr, "[BASAL-MI355X] total read pairs: %llu \ttotal time:  %.2f secs (GPU batches %.3f s)\n", (unsigned long long)n_pairs, now() - t0, t_gpu);
             fprintf(stderr, "\taligned pairs: %u, unique pairs: %u, non-unique pairs: %u\n\tunpaired read #1: %u, unique: %u, non-unique: %u\n\tunpaired read #2: %u, unique: %u, non-unique: %u\n",
                     pst[0], pst[1], pst[2], pst[3], pst[4], pst[5], pst[6], pst[7], pst[8]);
         }
-        basal_host_stale_free(tracker);
     } else {
-        std::vector<Rec> recs;
-        std::vector<uint8_t> bases;
-        std::vector<basal_read> descs;
-        std::vector<basal_result> results;
-        std::vector<basal_hit> stream;
-        std::vector<basal_stale> stales;
-        basal_stale_tracker_t *tracker = basal_host_stale_new(&P);
-        const int smode = P.report_repeat_hits == 2 ? BASAL_STREAM_BEST : BASAL_STREAM_NONE;
-        while (load_batch(ra, P, read_end, batch, 0, recs)) {
-            double h0 = now();
-            const size_t n = recs.size();
-            parallel_for(n, threads, [&](size_t b, size_t e, int) {
-                for (size_t i = b; i < e; i++) recs[i].qc_failed = basal_host_filter_read(&P, recs[i].seq.data(), recs[i].qual.data(), &recs[i].max_snp);
-            });
-            descs.assign(n, basal_read{});
-            bases.clear();
-            stales.clear();
-            basal_host_stale_begin_batch(tracker);
-            for (size_t i = 0; i < n; i++) {
-                basal_read &d = descs[i];
-                d.index = recs[i].index;
-                d.readset = 0;
-                d.stale_idx = BASAL_STALE_NONE;
-                if (recs[i].qc_failed) { d.len = 0; continue; }
-                uint32_t len = (uint32_t)strlen(recs[i].seq.data());
-                d.len = (uint16_t)len;
-                d.max_snp = (uint8_t)recs[i].max_snp;
-                d.seq_off = (uint32_t)bases.size();
-                bases.insert(bases.end(), recs[i].seq.begin(), recs[i].seq.begin() + len);
-                basal_stale se;
-                if (basal_host_stale_visit(tracker, recs[i].seq.data(), len, 0, 0, (uint32_t)i, &se)) {
-                    d.stale_idx = (uint32_t)stales.size();
-                    stales.push_back(se);
-                }
-            }
-            results.assign(n, basal_result{});
-            uint64_t cap = smode ? (uint64_t)n * 4 + 1024 : 0, used = 0;
-            double g0 = now();
-            for (;;) {
-                stream.resize(cap ? cap : 1);
-                uint8_t cy[2][2];
-                memcpy(cy, carry, 4);
-                int rc = basal_core_align_batch(core, bases.data(), bases.size(), descs.data(), (uint32_t)n, stales.data(), (uint32_t)stales.size(), smode, results.data(), stream.data(), cap, &used, cy);
-                if (rc == BASAL_EOVERFLOW) { cap = used + 1024; continue; }
-                if (rc) die(std::string("align_batch: ") + basal_last_error());
-                memcpy(carry, cy, 4);
-                break;
-            }
-            double g1 = now();
-            t_gpu += g1 - g0;
-            // format in input order; one output chunk per thread slice, written in slice order
-            std::vector<std::string> chunks((size_t)std::max(threads, 1));
-            std::vector<uint64_t> st((size_t)std::max(threads, 1) * 3, 0);
-            parallel_for(n, threads, [&](size_t b, size_t e, int tid) {
-                std::string &o = chunks[(size_t)tid];
-                std::vector<char> line(1 << 16);
-                for (size_t i = b; i < e; i++) {
-                    const Rec &rc_ = recs[i];
-                    const basal_result &rs = results[i];
-                    size_t need = 4096 + rc_.name.size() + 2 * rc_.seq.size() + (size_t)(rs.stream_n + 1) * (1024 + 2 * rc_.seq.size());
-                    if (line.size() < need) line.resize(need);
-                    int64_t w = basal_host_format_se(&P, R, rc_.name.c_str(), rc_.seq.data(), rc_.qual.data(), 0, rc_.qc_failed, &rs, stream.data(), line.data(), line.size());
-                    if (w < 0) die(std::string("format: ") + basal_last_error());
-                    o.append(line.data(), (size_t)w);
-                    if (!rc_.qc_failed && rs.best_level != 0xFF) {
-                        uint32_t sum = (uint32_t)rs.n_hit + rs.n_chit;
-                        if (sum == 1) { st[3 * tid]++; st[3 * tid + 1]++; }
-                        else { st[3 * tid + 2]++; if (P.report_repeat_hits) st[3 * tid]++; }
-                    }
-                }
-            });
-            for (auto &c : chunks) fwrite(c.data(), 1, c.size(), fo);
-            for (size_t t = 0; t < chunks.size(); t++) { n_aligned += st[3 * t]; n_unique += st[3 * t + 1]; n_multiple += st[3 * t + 2]; }
-            n_total += n;
-            t_host += (g0 - h0) + (now() - g1);
-            if (verbose >= 2) fprintf(stderr, "[BASAL-MI355X] %llu reads finished. %.2f secs passed\n", (unsigned long long)n_total, now() - t0);
+        SeStats st;
+        double t_wait = 0;
+        run_se(cli, core, out, st, t_wait);
+        out.close();
+        double t4 = now();
+        if (cli.verbose >= 1) {
+            const uint64_t tot = st.n_reads;
+            fprintf(stderr, "[BASAL-MI355X] total reads: %llu \ttotal time:  %.2f secs (align phase %.3f s = %.2f Mreads/s; GPU stage sums: H2D %.3f, read prep %.3f, align %.3f, SAM %.3f, D2H %.3f s)\n",
+                    (unsigned long long)tot, t4 - t0, t4 - t3, tot / (t4 - t3) / 1e6, st.ms[0] / 1e3, st.ms[1] / 1e3, st.ms[2] / 1e3, st.ms[3] / 1e3, st.ms[4] / 1e3);
+            fprintf(stderr, "\taligned reads: %llu (%.1f%%), unique reads: %llu (%.1f%%), %snon-unique reads: %llu (%.1f%%)\n", (unsigned long long)st.n_aligned,
+                    100.0 * st.n_aligned / (tot ? tot : 1), (unsigned long long)st.n_unique, 100.0 * st.n_unique / (tot ? tot : 1),
+                    P.report_repeat_hits == 0 ? "suppressed " : "", (unsigned long long)st.n_multiple, 100.0 * st.n_multiple / (tot ? tot : 1));
         }
-    }
-    double t4 = now();
-    if (piped) pclose(fo);
-    else if (fo != stdout) fclose(fo);
-    if (verbose >= 1 && !P.pairend) {
-        uint32_t tot = ra.index - read_start + 1;
-        fprintf(stderr, "[BASAL-MI355X] total reads: %u \ttotal time:  %.2f secs (align %.3f s: GPU batches %.3f s, host QC+SAM %.3f s)\n", tot, t4 - t0, t4 - t3, t_gpu, t_host);
-        fprintf(stderr, "\taligned reads: %llu (%.1f%%), unique reads: %llu (%.1f%%), %snon-unique reads: %llu (%.1f%%)\n", (unsigned long long)n_aligned,
-                100.0 * n_aligned / (tot ? tot : 1), (unsigned long long)n_unique, 100.0 * n_unique / (tot ? tot : 1), P.report_repeat_hits == 0 ? "suppressed " : "",
-                (unsigned long long)n_multiple, 100.0 * n_multiple / (tot ? tot : 1));
     }
     basal_core_destroy(core);
     basal_host_ref_free(R);

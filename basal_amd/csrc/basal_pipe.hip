@@ -73,8 +73,8 @@ struct basal_pipe {
     uint32_t next_batch = 0;
     hipEvent_t last_prep_done = nullptr;  // of the batch submitted last
     uint32_t read_end = 0xFFFFFFFFu;
-    char *d_names = nullptr;
-    uint32_t *d_name_off = nullptr;
+    bool broken = false;     // a batch was refused (or basal_pipe_stop): no acquire / submit / collect until basal_pipe_rewind
+    uint32_t rewind_to = 0;  // the batch number the pipe continues from after a rewind
 };
 
 extern "C" int basal_core_set_contig_names(basal_core_t *c, const char *const *names, uint32_t ncontig) {
@@ -207,6 +207,7 @@ extern "C" int basal_pipe_acquire(basal_pipe_t *p, uint8_t **blob, basal_rawread
     std::unique_lock<std::mutex> lk(p->m);
     if (p->acquired >= 0) { set_error("pipe_acquire: the acquired slot has not been submitted"); return BASAL_ESTATE; }
     for (;;) {
+        if (p->broken) { set_error("pipe_acquire: the pipe is stopped (a batch was refused): call basal_pipe_rewind"); return BASAL_ESTATE; }
         for (size_t i = 0; i < p->slots.size(); i++)
             if (p->slots[i].state == ST_FREE) {
                 p->slots[i].state = ST_ACQUIRED;
@@ -273,9 +274,11 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     if (!p) { set_error("pipe_submit: null argument"); return BASAL_EINVAL; }
     basal_core *c = p->c;
     int si;
+    bool broken;
     {
         std::lock_guard<std::mutex> lk(p->m);
         si = p->acquired;
+        broken = p->broken;
     }
     if (si < 0) { set_error("pipe_submit: no acquired slot (call basal_pipe_acquire first)"); return BASAL_ESTATE; }
     Slot &s = p->slots[(size_t)si];
@@ -286,6 +289,7 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
         p->cv.notify_all();
         return rc;
     };
+    if (broken) { set_error("pipe_submit: the pipe is stopped (a batch was refused): call basal_pipe_rewind"); return fail(BASAL_ESTATE); }
     if (nbytes > p->o.max_bytes || n > p->o.max_reads) { set_error("pipe_submit: batch larger than the pipe's max_bytes / max_reads"); return fail(BASAL_EINVAL); }
     if ((mode == MODE_PREPARED) != (p->o.output == BASAL_PIPE_OUT_RESULTS)) { set_error("pipe_submit: prepared reads go with BASAL_PIPE_OUT_RESULTS, text and records with BASAL_PIPE_OUT_SAM"); return fail(BASAL_EINVAL); }
     if (hipSetDevice(c->device) != hipSuccess) { set_error("pipe_submit: hipSetDevice failed"); return fail(BASAL_EDEVICE); }
@@ -366,6 +370,46 @@ extern "C" int basal_pipe_set_read_range(basal_pipe_t *p, uint32_t next_index, u
     return BASAL_OK;
 }
 
+extern "C" int basal_pipe_cancel(basal_pipe_t *p) {
+    if (!p) { set_error("pipe_cancel: null argument"); return BASAL_EINVAL; }
+    std::lock_guard<std::mutex> lk(p->m);
+    if (p->acquired >= 0) {
+        p->slots[(size_t)p->acquired].state = ST_FREE;
+        p->acquired = -1;
+        p->cv.notify_all();
+    }
+    return BASAL_OK;
+}
+
+extern "C" int basal_pipe_stop(basal_pipe_t *p) {
+    if (!p) { set_error("pipe_stop: null argument"); return BASAL_EINVAL; }
+    std::lock_guard<std::mutex> lk(p->m);
+    if (!p->broken) {
+        p->broken = true;
+        p->rewind_to = p->inflight.empty() ? p->next_batch : p->slots[(size_t)p->inflight.front()].batch_no;
+    }
+    p->cv.notify_all();
+    return BASAL_OK;
+}
+
+extern "C" int basal_pipe_rewind(basal_pipe_t *p) {
+    if (!p) { set_error("pipe_rewind: null argument"); return BASAL_EINVAL; }
+    std::lock_guard<std::mutex> lk(p->m);
+    HIP_TRYQ(hipSetDevice(p->c->device));
+    for (auto &s : p->slots) {
+        HIP_TRYQ(hipStreamSynchronize(s.st));
+        s.state = ST_FREE;
+        s.collecting = false;
+    }
+    p->inflight.clear();
+    p->acquired = p->held = -1;
+    if (p->broken) p->next_batch = p->rewind_to;
+    p->last_prep_done = nullptr;
+    p->broken = false;
+    p->cv.notify_all();
+    return BASAL_OK;
+}
+
 extern "C" int basal_pipe_release(basal_pipe_t *p) {
     if (!p) { set_error("pipe_release: null argument"); return BASAL_EINVAL; }
     std::lock_guard<std::mutex> lk(p->m);
@@ -388,6 +432,7 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             p->held = -1;
             p->cv.notify_all();
         }
+        if (p->broken) { set_error("pipe_collect: the pipe is stopped (a batch was refused): call basal_pipe_rewind"); return BASAL_ESTATE; }
         if (p->inflight.empty()) { set_error("pipe_collect: nothing in flight"); return BASAL_ESTATE; }
         si = p->inflight.front();
         p->slots[(size_t)si].collecting = true;
@@ -462,16 +507,10 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
         p->inflight.pop_front();
         s.collecting = false;
         if (ret == BASAL_EIO) {
-            // the batches submitted after this one were prepared as if it held no reads: drop them; the caller re-submits from here
-            // (the carry state this batch started from is still in the ring)
-            for (int j : p->inflight) {
-                hipStreamSynchronize(p->slots[(size_t)j].st);
-                p->slots[(size_t)j].state = ST_FREE;
-            }
-            p->inflight.clear();
-            p->next_batch = s.batch_no;
-            p->last_prep_done = nullptr;
-            hipStreamSynchronize(s.st);
+            // the batches submitted after this one were prepared as if it held no reads: the pipe stops here until the caller has
+            // quietened its submitter and called basal_pipe_rewind (the carry state this batch started from is still in the ring)
+            p->broken = true;
+            p->rewind_to = s.batch_no;
         }
         if (ret) s.state = ST_FREE;
         else { s.state = ST_HELD; p->held = si; }

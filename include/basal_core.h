@@ -243,12 +243,20 @@ int basal_pipe_submit_records(basal_pipe_t *p, uint64_t nblob, uint32_t n);
 int basal_pipe_submit_prepared(basal_pipe_t *p, uint64_t nbases, uint32_t n, uint32_t max_len);
 /* Wait for the OLDEST submitted batch. out/nbytes: its output in page-locked host memory (SAM text, or basal_result[n]),
  * valid until basal_pipe_release or the next collect; stats may be NULL. Returns BASAL_ESTATE when nothing is in flight.
- * BASAL_EIO: the batch's text is irregular (see submit_text); the batches submitted after it have been dropped and the
- * pipe continues from this batch: re-submit it (as records) and what followed it.
+ * BASAL_EIO: the batch's text is irregular (see submit_text); the pipe is now stopped, see basal_pipe_rewind: re-submit
+ * this batch (as records) and what followed it.
  * One thread may acquire/submit while another collects/releases. */
 int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *nbytes, basal_batch_stats *stats);
 /* Done with the output collect handed out: its slot can take a new batch (the next collect does this by itself). */
 int basal_pipe_release(basal_pipe_t *p);
+/* Give an acquired slot back without submitting it. */
+int basal_pipe_cancel(basal_pipe_t *p);
+/* After collect returned BASAL_EIO the pipe is stopped: acquire / submit / collect return BASAL_ESTATE (a blocked acquire wakes
+ * up) until the caller -- with its submitting thread quiet -- calls basal_pipe_rewind, which drops everything in flight and
+ * continues with the refused batch's number and the device state that batch started from. basal_pipe_stop stops the pipe the
+ * same way without a refused batch (continuing from the oldest batch in flight). */
+int basal_pipe_stop(basal_pipe_t *p);
+int basal_pipe_rewind(basal_pipe_t *p);
 /* -B / -E (ReadClass::InitIndex, reads.cpp:22-40): the number the next read gets, and the number at which loading stops
  * (text form: records from read_end on are ignored). Only with nothing in flight. */
 int basal_pipe_set_read_range(basal_pipe_t *p, uint32_t next_index, uint32_t read_end);

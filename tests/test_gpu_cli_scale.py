@@ -1,0 +1,124 @@
+"""The `basal` command line at scale, end to end, against the REFERENCE binary run with -p 1 on the same files (oracle/_ref/basal
+travels with the snapshot; the CPU oracle's CLI stands in if it is missing): SAM text identical byte for byte (minus @PG) on
+read files with what real files have -- N's, low-quality tails, adapter read-through, lower case, variable lengths, repeats."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import basal_amd as B
+import harness as H
+import oracle as orc
+
+sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+BASAL_BIN = os.path.join(H.ROOT, "basal_amd", "bin", "basal")
+
+
+def sam_digest(path):
+    h = hashlib.md5()
+    n = 0
+    with open(path, "rb") as f:
+        for line in f:
+            if not line.startswith(b"@PG"):
+                h.update(line)
+                n += not line.startswith(b"@")
+    return h.hexdigest(), n
+
+
+def make_files(tmp, rule, n_reads, read_len, seed, scale=0.02, repeat_copies=0, min_len=None, p_conv=0.95, **dirt):
+    import torch
+    import synth_gpu
+    import synth_files
+    dev = torch.device("cuda", 0)
+    p = B.Params(rule, ["-M", rule])
+    G = synth_gpu.make_genome(p, dev, scale=scale, seed=seed, repeat_copies=repeat_copies)
+    fa, fq = os.path.join(tmp, "g.fa"), os.path.join(tmp, "r.fq")
+    synth_files.write_fasta(fa, G)
+    frm = "ACGT".index(rule[0])
+    tos = [t for t in rule[2:] if t in "ACGT"]
+    to = "ACGT".index(tos[0]) if tos else frm
+    bases, _, _, _ = synth_gpu.make_reads(G, n_reads, dev, read_len=read_len, seed=seed + 1, conv_from=frm, conv_to=to, p_conv=p_conv if tos else 0.0)
+    seqs = bases.cpu().numpy().reshape(n_reads, read_len)
+    s, lens, q = synth_files.dirty(seqs, seed + 2, min_len=min_len, **dirt)
+    with open(fq, "wb") as f:
+        for b0 in range(0, n_reads, 250_000):
+            f.write(synth_files.fastq_bytes(s[b0:b0 + 250_000], lens[b0:b0 + 250_000], q[b0:b0 + 250_000], first=b0))
+    del G
+    torch.cuda.empty_cache()
+    return fa, fq
+
+
+def run_both(tmp, fa, fq, flags, env=None):
+    out, ref = os.path.join(tmp, "out.sam"), os.path.join(tmp, "ref.sam")
+    r = subprocess.run([BASAL_BIN, "-a", fq, "-d", fa] + flags + ["-p", "8", "-o", out], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr
+    checker = orc.REF_BIN if os.path.exists(orc.REF_BIN) else orc.CLI
+    c = subprocess.run([checker, "-a", fq, "-d", fa] + flags + ["-p", "1", "-o", ref], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr
+    got, want = sam_digest(out), sam_digest(ref)
+    assert got[1] == want[1], "record counts differ: %d vs %d" % (got[1], want[1])
+    assert got[0] == want[0], "SAM text differs from %s" % os.path.basename(checker)
+    return r.stderr, got[1]
+
+
+def test_cli_1m_dirty_reads_match_reference(tmp_path):
+    fa, fq = make_files(str(tmp_path), "C:T", 1_000_000, 100, seed=21)
+    log, n = run_both(str(tmp_path), fa, fq, ["-M", "C:T", "-S", "1", "-s", "12", "-u", "-q", "10", "-A", "AGATCGGAAGAGC"])
+    assert n == 1_000_000
+    assert "parsing it on the host" not in log
+
+
+def test_cli_repeats_r2_match_reference(tmp_path):
+    fa, fq = make_files(str(tmp_path), "C:T", 200_000, 100, seed=31, repeat_copies=200_000, n_rate=0.0, many_n_frac=0.0, lowq_frac=0.0, adapter_frac=0.0, lower_frac=0.0)
+    run_both(str(tmp_path), fa, fq, ["-M", "C:T", "-S", "3", "-s", "12", "-r", "2", "-w", "20", "-n", "1", "-k", "1e-3"])
+
+
+def test_cli_varlen_multiway_gap_match_reference(tmp_path):
+    fa, fq = make_files(str(tmp_path), "A:CGT", 200_000, 150, seed=41, min_len=40, p_conv=0.3)
+    run_both(str(tmp_path), fa, fq, ["-M", "A:CGT", "-S", "1", "-s", "12", "-g", "2", "-R", "-u"])
+
+
+def test_cli_many_small_text_batches(tmp_path):
+    """The reader's record cut and the device-side carry across ~1000 batches of a plain text file."""
+    fa, fq = make_files(str(tmp_path), "C:T", 60_000, 120, seed=51, min_len=36)
+    log, n = run_both(str(tmp_path), fa, fq, ["-M", "C:T", "-S", "1", "-s", "12", "-u"], env={"BASAL_PIPE_BYTES": "16384"})
+    assert n == 60_000
+
+
+@pytest.mark.parametrize("name", ["ct_basic", "varlen_trim", "edge_short", "fa_reads", "rep_r2_w10", "long_490_g1"])
+def test_cli_plain_text_input_small_batches(name, tmp_path):
+    """Uncompressed read files take the text path (the GPU finds the records); tiny batches exercise the reader's cut."""
+    import gzip
+    fa, fq, _, _ = H.fixture_paths(name)
+    plain = str(tmp_path / "reads.txt")
+    open(plain, "wb").write(gzip.open(fq, "rb").read())
+    out = str(tmp_path / "o.sam")
+    r = subprocess.run([BASAL_BIN, "-a", plain, "-d", fa] + H.MANIFEST[name]["flags"] + ["-o", out], capture_output=True, text=True,
+                       env=dict(os.environ, BASAL_PIPE_BYTES="8192"))
+    assert r.returncode == 0, r.stderr
+    assert "parsing it on the host" not in r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)
+
+
+def test_cli_irregular_text_falls_back_to_host_parsing(tmp_path):
+    """Blank lines between records: the reference's token reader takes them in its stride; the text path refuses the batch and the
+    CLI goes on parsing on the host from that batch's first byte -- same SAM."""
+    import gzip
+    name = "ct_basic"
+    fa, fq, _, _ = H.fixture_paths(name)
+    lines = gzip.open(fq, "rb").read().split(b"\n")
+    lines.insert(4 * 137, b"")  # after 137 records
+    plain = str(tmp_path / "reads.fq")
+    open(plain, "wb").write(b"\n".join(lines))
+    out = str(tmp_path / "o.sam")
+    r = subprocess.run([BASAL_BIN, "-a", plain, "-d", fa] + H.MANIFEST[name]["flags"] + ["-o", out], capture_output=True, text=True,
+                       env=dict(os.environ, BASAL_PIPE_BYTES="8192"))
+    assert r.returncode == 0, r.stderr
+    assert "parsing it on the host" in r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)

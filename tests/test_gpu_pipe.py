@@ -125,7 +125,8 @@ def test_pipe_irregular_text_is_refused_and_resubmitted():
     rc, msg, _ = pipe.collect()
     assert rc == -6 and "regular" in msg  # BASAL_EIO
     rc, msg, _ = pipe.collect()
-    assert rc == -4  # nothing in flight any more: the batch behind it was dropped
+    assert rc == -4 and "stopped" in msg  # BASAL_ESTATE until the caller rewinds; the batch behind the refused one is dropped then
+    pipe.rewind()
     # the caller parses the refused batch itself and goes on from there
     reads = orc.read_fastx(fq)
     blob, raw = make_records(reads[100:200], first_index=100)
