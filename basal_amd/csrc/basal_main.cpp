@@ -7,6 +7,7 @@
 // does FilterReads + alignment + SAM text, and the main thread writes the text in input order -- so the output equals the
 // reference's `-p 1` output.  Paired-end runs align both mates on the GPU and pair them on the host (PairAlign, pairs.cpp).
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -298,53 +299,67 @@ struct Cli {
     bool cpu_index = false;
 };
 
-// ---- output: a FILE* for pipes / stdout, positional parallel writes for regular files ----
+// ---- output: a FILE* for pipes / stdout; regular files are written through a shared mapping ----
+// (write()/pwrite() to one file take the inode lock, so threads do not add up; stores into a MAP_SHARED mapping fault their pages in
+// in parallel. The file is grown ahead in large steps and cut to its final size when it is closed.)
 struct Output {
     FILE *fo = stdout;
     bool piped = false, regular = false;
     int fd = -1;
-    uint64_t off = 0;
+    uint64_t off = 0, size = 0;
     int threads = 1;
     void write(const char *p, size_t n) {
         if (!n) return;
-        if (!regular || n < (8u << 20) || threads <= 1) {
-            if (regular) {
-                size_t done = 0;
-                while (done < n) {
-                    ssize_t w = pwrite(fd, p + done, n - done, (off_t)(off + done));
-                    if (w <= 0) die("write failed on the output file");
-                    done += (size_t)w;
-                }
-                off += n;
-            } else if (fwrite(p, 1, n, fo) != n) die("write failed on the output");
+        if (!regular) {
+            if (fwrite(p, 1, n, fo) != n) die("write failed on the output");
             return;
         }
-        // a regular file: every thread writes its own range (the page cache takes several GB/s per core, not more)
-        std::vector<std::thread> th;
-        std::atomic<bool> bad{false};
-        for (int t = 0; t < threads; t++)
-            th.emplace_back([&, t] {
-                size_t b = n * (size_t)t / (size_t)threads, e = n * (size_t)(t + 1) / (size_t)threads;
-                while (b < e) {
-                    ssize_t w = pwrite(fd, p + b, std::min<size_t>(e - b, 64u << 20), (off_t)(off + b));
-                    if (w <= 0) { bad = true; return; }
-                    b += (size_t)w;
-                }
-            });
-        for (auto &t : th) t.join();
-        if (bad) die("write failed on the output file");
+        if (off + n > size) {
+            size = off + n + (n < (64u << 20) ? (64u << 20) : 4 * (uint64_t)n);
+            if (ftruncate(fd, (off_t)size) != 0) die("cannot grow the output file");
+        }
+        const uint64_t page = 4096, m0 = off & ~(page - 1);
+        const size_t mlen = (size_t)(off + n - m0);
+        char *m = (char *)mmap(nullptr, mlen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)m0);
+        if (m == MAP_FAILED) {  // a file system without shared mappings: plain positional writes
+            size_t done = 0;
+            while (done < n) {
+                ssize_t w = pwrite(fd, p + done, n - done, (off_t)(off + done));
+                if (w <= 0) die("write failed on the output file");
+                done += (size_t)w;
+            }
+            off += n;
+            return;
+        }
+        char *dst = m + (off - m0);
+        const int nt = n < (4u << 20) ? 1 : threads;
+        if (nt <= 1) memcpy(dst, p, n);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([=] {
+                    const size_t b = n * (size_t)t / (size_t)nt, e = n * (size_t)(t + 1) / (size_t)nt;
+                    memcpy(dst + b, p + b, e - b);
+                });
+            for (auto &t : th) t.join();
+        }
+        munmap(m, mlen);
         off += n;
     }
     void close() {
         if (piped) pclose(fo);
-        else if (regular) ::close(fd);
+        else if (regular) { if (ftruncate(fd, (off_t)off) != 0) die("cannot set the size of the output file"); ::close(fd); }
         else if (fo != stdout) fclose(fo);
         else fflush(stdout);
     }
 };
 
 // =========================================================================== single-end: the GPU pipeline
-struct SeStats { uint64_t n_reads = 0, n_aligned = 0, n_unique = 0, n_multiple = 0; double ms[5] = {0, 0, 0, 0, 0}; };
+struct SeStats {
+    uint64_t n_reads = 0, n_aligned = 0, n_unique = 0, n_multiple = 0;
+    double ms[5] = {0, 0, 0, 0, 0};
+    double t_create = 0, t_read = 0, t_acquire = 0, t_write = 0, t_collect = 0;  // host side: where the wall clock went
+};
 
 // the last complete FASTQ / FASTA record in buf[0, n): returns the number of bytes that hold whole records. A FASTQ record
 // starts at a line that begins with '@' and whose next-but-one line begins with '+' (a quality line may begin with '@', but the
@@ -370,9 +385,10 @@ size_t cut_at_record(const char *buf, size_t n, bool fastq, bool at_eof) {
     return 0;
 }
 
-void run_se(Cli &cli, basal_core_t *core, Output &out, SeStats &st, double &t_wait_gpu) {
-    const basal_params &P = cli.P;
-    // input form
+struct SePlan { bool plain = false; basal_pipe_opts po; };
+
+// the input form and the batch geometry (before anything is staged: the pipeline's page-locked buffers are set up meanwhile)
+SePlan plan_se(const Cli &cli) {
     bool plain = false;
     uint64_t est_bytes = ~0ull;  // an estimate of the uncompressed input size, to size the batches of a small run
     {
@@ -390,7 +406,9 @@ void run_se(Cli &cli, basal_core_t *core, Output &out, SeStats &st, double &t_wa
     basal_pipe_opts po;
     memset(&po, 0, sizeof po);
     po.depth = 3;
-    po.max_reads = cli.batch ? (uint32_t)std::min<size_t>(cli.batch, 16u << 20) : (2u << 20);
+    // batches of half a million reads: a batch costs a few tenths of a millisecond of fixed GPU time, while page-locking its
+    // buffers costs host time in proportion to their size
+    po.max_reads = cli.batch ? (uint32_t)std::min<size_t>(cli.batch, 16u << 20) : (512u << 10);
     // bytes per batch: room for 100-base FASTQ records with short names at max_reads; longer records make batches of fewer reads
     po.max_bytes = std::min<uint64_t>((uint64_t)po.max_reads * 160 + (1u << 20), 0xF0000000ull);
     if (est_bytes < po.max_bytes) {  // a small input: small buffers (page-locking gigabytes takes longer than aligning a few thousand reads)
@@ -399,10 +417,18 @@ void run_se(Cli &cli, basal_core_t *core, Output &out, SeStats &st, double &t_wa
     }
     if (const char *e = getenv("BASAL_PIPE_BYTES")) po.max_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));  // (tests: many small batches)
     po.output = BASAL_PIPE_OUT_SAM;
-    basal_pipe_t *pipe = nullptr;
-    if (basal_pipe_create(core, &po, &pipe)) die(std::string("cannot create the pipeline: ") + basal_last_error());
     po.max_reads = (po.max_reads + 4095u) & ~4095u;
     po.max_bytes = (po.max_bytes + 4095ull) & ~4095ull;
+    SePlan pl;
+    pl.plain = plain;
+    pl.po = po;
+    return pl;
+}
+
+void run_se(Cli &cli, basal_pipe_t *pipe, const SePlan &plan, Output &out, SeStats &st, double &t_wait_gpu) {
+    const basal_params &P = cli.P;
+    bool plain = plan.plain;
+    const basal_pipe_opts po = plan.po;
     if (basal_pipe_set_read_range(pipe, cli.read_start - 1, cli.read_end)) die(basal_last_error());
 
     // reader thread -> pipe; the main thread collects and writes. A refused (irregular) text batch restarts the reader in
@@ -433,7 +459,10 @@ void run_se(Cli &cli, basal_core_t *core, Output &out, SeStats &st, double &t_wa
         while (!stop) {
             uint8_t *blob = nullptr;
             basal_rawread *raw = nullptr;
+            const double ta0 = now();
             if (basal_pipe_acquire(pipe, &blob, &raw)) break;  // the pipe was stopped (a batch was refused)
+            const double ta1 = now();
+            st.t_acquire += ta1 - ta0;
             if (stop) { basal_pipe_cancel(pipe); break; }
             size_t have = left.size();
             memcpy(blob, left.data(), have);
@@ -464,6 +493,7 @@ void run_se(Cli &cli, basal_core_t *core, Output &out, SeStats &st, double &t_wa
             }
             off += want;
             have += want;
+            st.t_read += now() - ta1;
             const bool at_eof = off >= fsize;
             if (first) {
                 size_t p = 0;
@@ -585,14 +615,15 @@ void run_se(Cli &cli, basal_core_t *core, Output &out, SeStats &st, double &t_wa
             std::lock_guard<std::mutex> lk(qm);
             if (!submitted.empty()) submitted.pop_front();
         }
+        const double tw0 = now();
         out.write((const char *)data, (size_t)nbytes);
+        st.t_write += now() - tw0;
         st.n_reads += bs.n_reads; st.n_aligned += bs.n_aligned; st.n_unique += bs.n_unique; st.n_multiple += bs.n_multiple;
         st.ms[0] += bs.ms_h2d; st.ms[1] += bs.ms_prep; st.ms[2] += bs.ms_align; st.ms[3] += bs.ms_format; st.ms[4] += bs.ms_d2h;
         if (cli.verbose >= 2) fprintf(stderr, "[BASAL-MI355X] %llu reads finished.\n", (unsigned long long)st.n_reads);
     }
     rt.join();
     if (!reader_err.empty()) die(reader_err);
-    basal_pipe_destroy(pipe);
 }
 
 // =========================================================================== paired-end: GPU alignment, host pairing
@@ -760,12 +791,26 @@ int main(int argc, char **argv) {
     if (cli.threads < 1) cli.threads = 1;
 
     double t0 = now();
+    basal_core_t *core = nullptr;
+    if (basal_core_create(&P, cli.device, &core)) die(std::string("cannot create the GPU core: ") + basal_last_error());
+    // single-end: the pipeline's buffers are page-locked by a helper thread while the reference is read and staged
+    SePlan plan;
+    basal_pipe_t *pipe = nullptr;
+    std::thread pipe_thread;
+    std::string pipe_err;
+    double t_pipe = 0;
+    if (!P.pairend) {
+        plan = plan_se(cli);
+        pipe_thread = std::thread([&] {
+            const double a0 = now();
+            if (basal_pipe_create(core, &plan.po, &pipe)) pipe_err = basal_last_error();
+            t_pipe = now() - a0;
+        });
+    }
     if (cli.verbose >= 1) fprintf(stderr, "[BASAL-MI355X] loading reference file: %s\n", cli.ref_file.c_str());
     basal_ref_t *R = nullptr;
     if (basal_host_ref_load(&P, cli.ref_file.c_str(), &R)) die(basal_last_error());
     double t1 = now();
-    basal_core_t *core = nullptr;
-    if (basal_core_create(&P, cli.device, &core)) die(std::string("cannot create the GPU core: ") + basal_last_error());
     uint32_t mk = 0;
     if (cli.cpu_index) {
         if (basal_host_ref_build_index(R, &P, cli.threads)) die(basal_last_error());
@@ -784,7 +829,7 @@ int main(int argc, char **argv) {
 
     // -o x.bam pipes SAM through an external `samtools view -bS -`, like the reference (main.cpp:504-513)
     Output out;
-    out.threads = std::max(1, std::min(cli.threads, 8));
+    out.threads = std::max(1, std::min(cli.threads, 16));
     if (!cli.out_file.empty()) {
         if (cli.out_file.size() > 4 && cli.out_file.compare(cli.out_file.size() - 4, 4, ".bam") == 0) {
             std::string cmd = "samtools view -bS - >" + cli.out_file;
@@ -822,18 +867,28 @@ int main(int argc, char **argv) {
     } else {
         SeStats st;
         double t_wait = 0;
-        run_se(cli, core, out, st, t_wait);
+        pipe_thread.join();
+        if (!pipe) die("cannot create the pipeline: " + pipe_err);
+        st.t_create = t_pipe;
+        t3 = now();
+        run_se(cli, pipe, plan, out, st, t_wait);
         out.close();
         double t4 = now();
         if (cli.verbose >= 1) {
             const uint64_t tot = st.n_reads;
             fprintf(stderr, "[BASAL-MI355X] total reads: %llu \ttotal time:  %.2f secs (align phase %.3f s = %.2f Mreads/s; GPU stage sums: H2D %.3f, read prep %.3f, align %.3f, SAM %.3f, D2H %.3f s)\n",
                     (unsigned long long)tot, t4 - t0, t4 - t3, tot / (t4 - t3) / 1e6, st.ms[0] / 1e3, st.ms[1] / 1e3, st.ms[2] / 1e3, st.ms[3] / 1e3, st.ms[4] / 1e3);
+            fprintf(stderr, "\thost side: pipeline set-up %.3f s (beside the reference load), reading %.3f s, waiting for a free batch slot %.3f s, waiting for results %.3f s, writing %.3f s\n", st.t_create, st.t_read,
+                    st.t_acquire, t_wait, st.t_write);
             fprintf(stderr, "\taligned reads: %llu (%.1f%%), unique reads: %llu (%.1f%%), %snon-unique reads: %llu (%.1f%%)\n", (unsigned long long)st.n_aligned,
                     100.0 * st.n_aligned / (tot ? tot : 1), (unsigned long long)st.n_unique, 100.0 * st.n_unique / (tot ? tot : 1),
                     P.report_repeat_hits == 0 ? "suppressed " : "", (unsigned long long)st.n_multiple, 100.0 * st.n_multiple / (tot ? tot : 1));
         }
     }
+    fflush(stdout);
+    fflush(stderr);
+    if (!getenv("BASAL_CLEAN_EXIT")) _exit(0);  // everything is written: leave the gigabytes of page-locked and device memory to the OS
+    if (pipe) basal_pipe_destroy(pipe);
     basal_core_destroy(core);
     basal_host_ref_free(R);
     return 0;

@@ -124,7 +124,6 @@ extern "C" void basal_pipe_destroy(basal_pipe_t *p) {
 
 extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basal_pipe_t **out) {
     if (!c || !out) { set_error("pipe_create: null argument"); return BASAL_EINVAL; }
-    if (!c->have_ref || !c->have_index) { set_error("pipe_create: stage the reference and the index first"); return BASAL_ESTATE; }
     basal_pipe_opts op;
     memset(&op, 0, sizeof op);
     if (o) op = *o;
@@ -136,7 +135,6 @@ extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basa
     op.max_bytes = (op.max_bytes + 4095ull) & ~4095ull;
     if (op.max_bytes >= 0xFFFFF000ull) { set_error("pipe_create: max_bytes must stay below 4 GiB (32-bit offsets inside a batch)"); return BASAL_EINVAL; }
     if (op.output > BASAL_PIPE_OUT_RESULTS) { set_error("pipe_create: bad output mode"); return BASAL_EINVAL; }
-    if (op.output == BASAL_PIPE_OUT_SAM && (!c->d_names || c->n_names != c->ncontig)) { set_error("pipe_create: SAM output needs basal_core_set_contig_names first"); return BASAL_ESTATE; }
     HIP_TRYQ(hipSetDevice(c->device));
     int rc = basal_ensure_launch_geometry(c);
     if (rc) return rc;
@@ -144,8 +142,6 @@ extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basa
     p->c = c;
     p->o = op;
     prep_make_const(c->p, p->k);
-    p->sh.names = c->d_names;
-    p->sh.name_off = c->d_name_off;
     p->sh.ncarry = op.depth + 1;
     p->slots.resize(op.depth);
 #define TRYD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); basal_pipe_destroy(p); return e_ == hipErrorOutOfMemory ? BASAL_ENOMEM : BASAL_EDEVICE; } } while (0)
@@ -290,6 +286,11 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
         return rc;
     };
     if (broken) { set_error("pipe_submit: the pipe is stopped (a batch was refused): call basal_pipe_rewind"); return fail(BASAL_ESTATE); }
+    // (the pipe may have been created while the reference was still being staged: page-locking its buffers takes a while)
+    if (!c->have_ref || !c->have_index) { set_error("pipe_submit: stage the reference and the index first"); return fail(BASAL_ESTATE); }
+    if (p->o.output == BASAL_PIPE_OUT_SAM && (!c->d_names || c->n_names != c->ncontig)) { set_error("pipe_submit: SAM output needs basal_core_set_contig_names first"); return fail(BASAL_ESTATE); }
+    p->sh.names = c->d_names;
+    p->sh.name_off = c->d_name_off;
     if (nbytes > p->o.max_bytes || n > p->o.max_reads) { set_error("pipe_submit: batch larger than the pipe's max_bytes / max_reads"); return fail(BASAL_EINVAL); }
     if ((mode == MODE_PREPARED) != (p->o.output == BASAL_PIPE_OUT_RESULTS)) { set_error("pipe_submit: prepared reads go with BASAL_PIPE_OUT_RESULTS, text and records with BASAL_PIPE_OUT_SAM"); return fail(BASAL_EINVAL); }
     if (hipSetDevice(c->device) != hipSuccess) { set_error("pipe_submit: hipSetDevice failed"); return fail(BASAL_EDEVICE); }

@@ -35,6 +35,27 @@ namespace {
 
 __device__ __forceinline__ bool is_ws(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }  // what iostream's >> skips
 
+// Bytes of a global buffer served from aligned 16-byte chunks: a thread that walks a string byte by byte (in either direction)
+// issues one load per 16 bytes instead of one per byte. The chunk holding a valid byte lies inside the buffer's allocation
+// (hipMalloc aligns to 256 bytes and the buffers are padded).
+struct Bytes16 {
+    const uint8_t *base;
+    unsigned long long cur = ~0ull;
+    uint32_t w[4];
+    __device__ __forceinline__ explicit Bytes16(const uint8_t *b) : base(b) {}
+    __device__ __forceinline__ uint32_t get(uint32_t i) {
+        const unsigned long long a = (unsigned long long)(base + i), c = a & ~15ull;
+        if (c != cur) {
+            const uint4 v = *(const uint4 *)c;
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            cur = c;
+        }
+        const uint32_t k = (uint32_t)(a & 15u);
+        const uint32_t d = k < 8 ? (k < 4 ? w[0] : w[1]) : (k < 12 ? w[2] : w[3]);
+        return (d >> ((k & 3u) * 8)) & 0xffu;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ text -> lines -> raw reads
 constexpr int kTextBlock = 4096;  // bytes of text per 256-thread block, 16 per thread
 
@@ -102,24 +123,25 @@ __global__ __launch_bounds__(256) void build_raw(const uint8_t *__restrict__ tex
         memset(&rr, 0, sizeof rr);
         if (!irr) {
             if (text[lb[0]] != (fasta ? '>' : '@')) irr = true;
+            Bytes16 tb(text);
             // name: the first token behind the marker (reads.cpp:53-55 `>>ch; >>name; getline`)
             uint32_t p = lb[0] + 1;
-            while (p < le[0] && !is_ws(text[p])) p++;
+            while (p < le[0] && !is_ws(tb.get(p))) p++;
             const uint32_t nlen = p - (lb[0] + 1);
             if (nlen == 0 || nlen > 0xffffu) irr = true;
             rr.name_off = lb[0] + 1;
             rr.name_len = (uint16_t)nlen;
             // bases: one token, then only white space up to the end of the line
             p = lb[1];
-            while (p < le[1] && !is_ws(text[p])) p++;
+            while (p < le[1] && !is_ws(tb.get(p))) p++;
             uint32_t sl = p - lb[1];
-            for (; p < le[1]; p++) if (!is_ws(text[p])) irr = true;
+            for (; p < le[1]; p++) if (!is_ws(tb.get(p))) irr = true;
             uint32_t ql = 0;
             if (!fasta) {
                 p = lb[3];
-                while (p < le[3] && !is_ws(text[p])) p++;
+                while (p < le[3] && !is_ws(tb.get(p))) p++;
                 ql = p - lb[3];
-                for (; p < le[3]; p++) if (!is_ws(text[p])) irr = true;
+                for (; p < le[3]; p++) if (!is_ws(tb.get(p))) irr = true;
                 rr.qual_off = lb[3];
             }
             if (sl > 0xffffu || ql > 0xffffu) irr = true;
@@ -140,9 +162,9 @@ __global__ __launch_bounds__(256) void build_raw(const uint8_t *__restrict__ tex
 
 // ------------------------------------------------------------------------------------------------ FilterReads
 // the quality character the reference holds after TrimLowQual's shift (align.cpp:58-61)
-__device__ __forceinline__ uint32_t qual_char(const PrepConst &k, const uint8_t *q, bool fill, uint32_t i) {
+__device__ __forceinline__ uint32_t qual_char(const PrepConst &k, Bytes16 &q, bool fill, uint32_t i) {
     const uint32_t shift = k.zero_qual - '!';
-    return ((fill ? k.zero_qual + k.default_qual : (uint32_t)q[i]) - shift) & 0xffu;
+    return ((fill ? k.zero_qual + k.default_qual : q.get(i)) - shift) & 0xffu;
 }
 
 __global__ __launch_bounds__(256) void filter_reads(PrepConst k, const uint8_t *__restrict__ text, const uint8_t *__restrict__ reg_alphabet,
@@ -156,7 +178,7 @@ __global__ __launch_bounds__(256) void filter_reads(PrepConst k, const uint8_t *
         uint32_t cls = 3;
         if (r < n) {
             const basal_rawread rr = raw[r];
-            const uint8_t *seq = text + rr.seq_off, *qual = text + rr.qual_off;
+            Bytes16 seq(text + rr.seq_off), qual(text + rr.qual_off);
             uint32_t L = rr.seq_len;
             uint32_t x = k.max_snp_num < 100 ? k.max_snp_num : (uint32_t)((k.max_snp_num - 100) / 100.0 * L + 0.5);  // align.cpp:550-551
             if (k.gap > 0) x += 1 + k.gap;
@@ -171,7 +193,7 @@ __global__ __launch_bounds__(256) void filter_reads(PrepConst k, const uint8_t *
                 for (uint32_t pos = k.K + k.I - 1; pos + 4 < L; pos++) {
                     uint32_t mis = 0, j = 0;
                     for (; j < al && pos + j < L; j++)
-                        if ((mis += (k.adapter[a][j] != seq[pos + j])) > 4) break;
+                        if ((mis += (k.adapter[a][j] != seq.get(pos + j))) > 4) break;
                     if (j >= mis * 5 && j > 3) {
                         L = pos;
                         if (qlen > pos) qlen = pos;
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(256) void filter_reads(PrepConst k, const uint8_t *
             if (!failed && L < k.min_read_size) failed = true;
             if (!failed) {  // CountNs (align.cpp:40-47)
                 uint32_t ns = 0;
-                for (uint32_t i = 0; i < L; i++) ns += !reg_alphabet[seq[i]];
+                for (uint32_t i = 0; i < L; i++) ns += !reg_alphabet[seq.get(i)];
                 if (ns > k.max_ns) failed = true;
             }
             basal_read d;
@@ -453,26 +475,57 @@ struct CountSink {
     __device__ __forceinline__ void skip(uint32_t l) { n += l; }
     static constexpr bool kWrites = false;
 };
+// bytes are gathered into 16-byte chunks aligned at the destination and leave as one store each; the partial chunks at the two ends of
+// a read's text (their other bytes belong to the neighbouring reads) leave byte by byte
 struct WriteSink {
-    uint8_t *p;
-    __device__ __forceinline__ void ch(uint32_t c) { *p++ = (uint8_t)c; }
+    uint8_t *p;                 // next byte to be written
+    unsigned long long lo, hi;  // the chunk being gathered (bytes [p & ~15, p)); selects and shifts only -- the lanes of a wave are at
+                                // different byte positions, and a branch per position would serialise them
+    uint32_t have;              // 1: every byte of the current chunk from its start on was produced here (it may leave as one store)
+    __device__ __forceinline__ explicit WriteSink(uint8_t *dst) : p(dst), lo(0), hi(0), have(((unsigned long long)dst & 15u) == 0) {}
+    __device__ __forceinline__ void ch(uint32_t c) {
+        const uint32_t k = (uint32_t)((unsigned long long)p & 15u);
+        const unsigned long long v = (unsigned long long)(c & 0xffu) << ((k & 7u) * 8);
+        lo |= k < 8 ? v : 0ull;
+        hi |= k < 8 ? 0ull : v;
+        if (!have) *p = (uint8_t)c;  // the head of the text, up to the first chunk boundary
+        p++;
+        if (k == 15) {
+            if (have) *(uint4 *)(p - 16) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            have = 1;
+            lo = hi = 0;
+        }
+    }
+    __device__ __forceinline__ void flush() {  // the tail: the bytes gathered in an unfinished chunk
+        if (!have) return;
+        const uint32_t k = (uint32_t)((unsigned long long)p & 15u);
+        uint8_t *q = p - k;
+        for (uint32_t i = 0; i < k; i++) q[i] = (uint8_t)((i < 8 ? lo : hi) >> ((i & 7u) * 8));
+    }
     static constexpr bool kWrites = true;
 };
 
 template <class S>
-__device__ __forceinline__ void put_num(S &o, long long v) {
+__device__ __forceinline__ void put_num(S &o, long long v) {  // |v| < 2^32; no digit buffer (a private array would live in scratch memory)
     if (v < 0) { o.ch('-'); v = -v; }
-    char b[20];
-    int l = 0;
-    do { b[l++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (l) o.ch(b[--l]);
+    uint32_t u = (uint32_t)v;
+    bool started = false;
+#pragma unroll
+    for (uint32_t d = 1000000000u; d >= 1; d /= 10) {
+        const uint32_t q = u / d;
+        u -= q * d;
+        if (q || started || d == 1) { o.ch('0' + q); started = true; }
+    }
 }
 template <class S>
 __device__ __forceinline__ void put_lit(S &o, const char *s) { for (; *s; s++) o.ch(*s); }
 template <class S>
 __device__ __forceinline__ void put_bytes(S &o, const uint8_t *s, uint32_t l) {
     if constexpr (!S::kWrites) o.skip(l);
-    else for (uint32_t i = 0; i < l; i++) o.ch(s[i]);
+    else {
+        Bytes16 r(s);
+        for (uint32_t i = 0; i < l; i++) o.ch(r.get(i));
+    }
 }
 
 __device__ __forceinline__ uint32_t comp_char(uint32_t c) {  // rev_char, param.cpp:146-156
@@ -498,13 +551,13 @@ struct FmtCtx {
 };
 
 template <class S>
-__device__ void put_seq_qual(S &o, const FmtCtx &f, const basal_rawread &rr, const ReadAux &a, bool rev) {
-    const uint8_t *seq = f.text + rr.seq_off, *qual = f.text + rr.qual_off;
+__device__ __forceinline__ void put_seq_qual(S &o, const FmtCtx &f, const basal_rawread &rr, const ReadAux &a, bool rev) {
     const uint32_t len = a.seq_len, qlen = a.qual_len;
     if constexpr (!S::kWrites) { o.skip(len + 1 + qlen); return; }
     else {
-        if (!rev) for (uint32_t i = 0; i < len; i++) o.ch(seq[i]);
-        else for (uint32_t i = 0; i < len; i++) o.ch(comp_char(seq[len - 1 - i]));
+        Bytes16 seq(f.text + rr.seq_off), qual(f.text + rr.qual_off);
+        if (!rev) for (uint32_t i = 0; i < len; i++) o.ch(seq.get(i));
+        else for (uint32_t i = 0; i < len; i++) o.ch(comp_char(seq.get(len - 1 - i)));
         o.ch('\t');
         if (!rev) for (uint32_t i = 0; i < qlen; i++) o.ch(qual_char(f.k, qual, a.qual_fill, i));
         else for (uint32_t i = 0; i < qlen; i++) o.ch(qual_char(f.k, qual, a.qual_fill, qlen - 1 - i));
@@ -513,7 +566,7 @@ __device__ void put_seq_qual(S &o, const FmtCtx &f, const basal_rawread &rr, con
 
 // n <= 0: unmapped (n < 0: failed QC); else one alignment record
 template <class S>
-__device__ void put_record(S &o, const FmtCtx &f, const basal_rawread &rr, const ReadAux &a, uint32_t chain, int n, uint32_t level, const basal_hit &h) {
+__device__ __forceinline__ void put_record(S &o, const FmtCtx &f, const basal_rawread &rr, const ReadAux &a, uint32_t chain, int n, uint32_t level, const basal_hit &h) {
     int flag = (int)(0x40 * rr.readset);
     if (n <= 0) {
         if (!f.k.out_unmap) return;
@@ -549,36 +602,52 @@ __device__ void put_record(S &o, const FmtCtx &f, const basal_rawread &rr, const
         const uint32_t loc = h.loc;
         if constexpr (!S::kWrites) o.skip((loc >= 2) + (loc >= 1) + len + 2);
         else {
+            // the four letters as one word (a per-lane index into the by-value argument struct would put the struct into scratch memory)
+            const uint32_t nt4 = (uint32_t)(uint8_t)f.k.useful_nt[0] | ((uint32_t)(uint8_t)f.k.useful_nt[1] << 8) | ((uint32_t)(uint8_t)f.k.useful_nt[2] << 16) |
+                                 ((uint32_t)(uint8_t)f.k.useful_nt[3] << 24);
+            unsigned long long wcur = ~0ull, word = 0;  // one reference word serves 32 bases
+            auto base_at = [&](uint32_t xx) {
+                if ((xx >> 5) != wcur) { wcur = xx >> 5; word = s[wcur]; }
+                return (nt4 >> (8 * (uint32_t)((word >> (62 - 2 * (xx & 31))) & 3))) & 0xffu;
+            };
             for (uint32_t q = 2; q > 0; q--)
-                if (loc >= q) { const uint32_t xx = loc - q; o.ch((uint32_t)f.k.useful_nt[(s[xx >> 5] >> (62 - 2 * (xx & 31))) & 3] + 32); }
-            for (uint32_t q = 0; q < len + 2; q++) { const uint32_t xx = loc + q; o.ch((uint32_t)f.k.useful_nt[(s[xx >> 5] >> (62 - 2 * (xx & 31))) & 3] + (q >= len ? 32 : 0)); }
+                if (loc >= q) o.ch(base_at(loc - q) + 32);
+            for (uint32_t q = 0; q < len + 2; q++) o.ch(base_at(loc + q) + (q >= len ? 32 : 0));
         }
     }
     put_lit(o, "\tZS:Z:"); o.ch((h.chr & 1) ? '-' : '+'); o.ch(chain ? '-' : '+'); o.ch('\n');
 }
 
-// StringAlign (align.cpp:583-612) with the GPU's choice of hit
+// StringAlign (align.cpp:583-612) with the GPU's choice of hit. One call site of put_record, everything inlined into the two
+// kernels: a call that passes the by-value argument struct by reference would make every lane copy the struct to scratch memory.
 template <class S>
-__device__ void put_read(S &o, const FmtCtx &f, uint32_t r, uint32_t *kind) {
+__device__ __forceinline__ void put_read(S &o, const FmtCtx &f, uint32_t r, uint32_t *kind) {
     const basal_rawread rr = f.raw[r];
     const ReadAux a = f.aux[r];
-    basal_hit none;
-    memset(&none, 0, sizeof none);
+    basal_hit h;
+    memset(&h, 0, sizeof h);
     *kind = 0;
-    if (a.qc_failed) { put_record(o, f, rr, a, 0, -1, 0, none); return; }
-    const basal_result rs = f.res[r];
-    if (rs.best_level == 0xFF) { put_record(o, f, rr, a, 0, 0, 0, none); return; }
-    const uint32_t sum = (uint32_t)rs.n_hit + rs.n_chit, ii = rs.best_level;
-    *kind = sum == 1 ? 1 : 2;
-    if (sum == 1) put_record(o, f, rr, a, rs.best.chain, 1, ii, rs.best);
-    else if (f.k.report_repeat_hits == 1) put_record(o, f, rr, a, rs.best.chain, (int)sum, ii, rs.best);
-    else if (f.k.report_repeat_hits == 2) {
-        if (rs.status == BASAL_READ_OVERFLOW || rs.stream_n != sum) { *kind |= 4; return; }  // stream too small: the batch is redone
-        for (uint32_t j = 0; j < sum; j++) {
-            const basal_hit h = f.stream[rs.stream_first + j];
-            put_record(o, f, rr, a, h.chain, (int)sum, ii, h);
+    int n = 0;
+    uint32_t nrec = 1, level = 0, chain = 0, first = 0;
+    bool from_stream = false;
+    if (a.qc_failed) n = -1;
+    else {
+        const basal_result rs = f.res[r];
+        if (rs.best_level != 0xFF) {
+            const uint32_t sum = (uint32_t)rs.n_hit + rs.n_chit;
+            level = rs.best_level;
+            *kind = sum == 1 ? 1 : 2;
+            if (sum == 1 || f.k.report_repeat_hits == 1) { n = (int)sum; h = rs.best; chain = rs.best.chain; }
+            else if (f.k.report_repeat_hits == 2) {
+                if (rs.status == BASAL_READ_OVERFLOW || rs.stream_n != sum) { *kind |= 4; return; }  // stream too small: the batch is redone
+                n = (int)sum; nrec = sum; first = rs.stream_first; from_stream = true;
+            }  // -r 0: one unmapped record (n = 0)
         }
-    } else put_record(o, f, rr, a, 0, 0, ii, none);
+    }
+    for (uint32_t j = 0; j < nrec; j++) {
+        if (from_stream) { h = f.stream[first + j]; chain = h.chain; }
+        put_record(o, f, rr, a, chain, n, level, h);
+    }
 }
 
 __global__ __launch_bounds__(256) void sam_lengths(FmtCtx f, const uint32_t *__restrict__ n_ptr, uint32_t n_host, uint32_t max_reads,
@@ -612,9 +681,10 @@ __global__ __launch_bounds__(256) void sam_write(FmtCtx f, const uint32_t *__res
     if (out_off[n] > out_cap) return;  // the host grows the buffer and queues this kernel again
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
         if (out_off[r + 1] == out_off[r]) continue;
-        WriteSink o{out + out_off[r]};
+        WriteSink o(out + out_off[r]);
         uint32_t kind;
         put_read(o, f, r, &kind);
+        o.flush();
     }
 }
 
