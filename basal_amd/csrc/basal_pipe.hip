@@ -1,9 +1,11 @@
 // basal_pipe.hip -- the batch pipeline around the align kernel: raw read text (or raw read tables, or prepared reads) in
 // page-locked host buffers -> HBM -> device-side parse / FilterReads / inherited-state table (basal_prep.hip) -> align kernels (one
-// launch per read-length class) -> device-side SAM text -> page-locked host buffer.  Every batch slot has its own HIP stream, so the
-// H2D copy of batch k+1 and the D2H copy of batch k-1 overlap the kernels of batch k; the only cross-slot ordering is the small
-// carry state (what later reads inherit from earlier ones), chained through one event per batch.  Nothing is decided on the host
-// from device data until a batch is collected: batch sizes the GPU counted itself (text form) stay on the GPU.
+// launch per read-length class) -> device-side SAM text -> page-locked host buffer.  Three HIP streams, one per resource: copies in
+// (PCIe down), kernels, copies out (PCIe up); a batch moves from one to the next through events, so the H2D copy of batch k+1 and the
+// D2H copy of batch k-1 overlap the kernels of batch k while each resource serves the batches in order at its full rate (batches
+// sharing a resource -- two persistent align grids on the GPU, three copies on the link -- only finish later, all of them).  The
+// kernel stream also orders the small carry state (what later reads inherit from earlier ones).  Nothing is decided on the host from
+// device data until a batch is collected: batch sizes the GPU counted itself (text form) stay on the GPU.
 //
 // Replaces, for the `basal` command line, the reference's per-thread loop LoadBatchReads -> ImportBatchReads -> Do_Batch ->
 // write _str_align (main.cpp:60-92).
@@ -33,7 +35,7 @@ namespace {
         }                                                              \
     } while (0)
 
-enum { EV_START = 0, EV_H2D, EV_PREP, EV_ALIGN, EV_FORMAT, EV_COUNTERS, EV_OUT, EV_N };
+enum { EV_START = 0, EV_H2D, EV_COMP0, EV_PREP, EV_ALIGN, EV_FORMAT, EV_COUNTERS, EV_OUT0, EV_OUT, EV_N };
 enum { MODE_TEXT = 0, MODE_RECORDS, MODE_PREPARED };
 enum { ST_FREE = 0, ST_ACQUIRED, ST_INFLIGHT, ST_HELD };
 
@@ -45,9 +47,7 @@ struct Slot {
     size_t h_out_cap = 0;
     BatchCounters *h_cnt = nullptr;
     unsigned int *h_guard = nullptr;
-    hipStream_t st = nullptr;
     hipEvent_t ev[EV_N] = {nullptr};
-    hipEvent_t prep_done = nullptr;
     int state = ST_FREE;
     uint32_t batch_no = 0;
     int mode = MODE_TEXT;
@@ -71,7 +71,7 @@ struct basal_pipe {
     int acquired = -1, held = -1;
     std::deque<int> inflight;
     uint32_t next_batch = 0;
-    hipEvent_t last_prep_done = nullptr;  // of the batch submitted last
+    hipStream_t st_in = nullptr, st_comp = nullptr, st_out = nullptr, st_cnt = nullptr;  // st_cnt: the few bytes of counters per batch (the host sizes the output copy from them; they must not queue behind an output copy)
     uint32_t read_end = 0xFFFFFFFFu;
     bool broken = false;     // a batch was refused (or basal_pipe_stop): no acquire / submit / collect until basal_pipe_rewind
     uint32_t rewind_to = 0;  // the batch number the pipe continues from after a rewind
@@ -108,8 +108,6 @@ static void free_slot(Slot &s) {
     if (s.h_cnt) hipHostFree(s.h_cnt);
     if (s.h_guard) hipHostFree(s.h_guard);
     for (int i = 0; i < EV_N; i++) if (s.ev[i]) hipEventDestroy(s.ev[i]);
-    if (s.prep_done) hipEventDestroy(s.prep_done);
-    if (s.st) hipStreamDestroy(s.st);
     s = Slot();
 }
 
@@ -119,6 +117,10 @@ extern "C" void basal_pipe_destroy(basal_pipe_t *p) {
     hipDeviceSynchronize();
     for (auto &s : p->slots) free_slot(s);
     for (uint32_t i = 0; i < p->sh.ncarry; i++) hipFree(p->sh.carry[i]);
+    if (p->st_in) hipStreamDestroy(p->st_in);
+    if (p->st_comp) hipStreamDestroy(p->st_comp);
+    if (p->st_out) hipStreamDestroy(p->st_out);
+    if (p->st_cnt) hipStreamDestroy(p->st_cnt);
     delete p;
 }
 
@@ -189,9 +191,21 @@ extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basa
         TRYD(hipHostMalloc(&s.h_out, s.h_out_cap, hipHostMallocDefault));
         TRYD(hipHostMalloc(&s.h_cnt, sizeof(BatchCounters), hipHostMallocDefault));
         TRYD(hipHostMalloc(&s.h_guard, 24 * sizeof(unsigned int), hipHostMallocDefault));
-        TRYD(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
         for (int i = 0; i < EV_N; i++) TRYD(hipEventCreate(&s.ev[i]));
-        TRYD(hipEventCreateWithFlags(&s.prep_done, hipEventDisableTiming));
+    }
+    {
+        // HIP multiplexes streams onto a few hardware queues (4 by default), and two streams on one queue run in submission order --
+        // the copy-in stream and the kernel stream sharing a queue would undo the whole pipeline (measured: exactly that happened).
+        // Streams of different priority get queues of their own, so the four streams are spread over the priority levels.
+        int lo = 0, hi = 0;
+        TRYD(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least urgent (numerically largest), hi = most urgent
+        const char *e = getenv("BASAL_PIPE_PRIO");
+        int pin = hi, pcomp = (lo + hi) / 2, pout = lo, pcnt = hi;
+        if (e && strlen(e) == 4) { auto lv = [&](char ch) { return ch == 'h' ? hi : ch == 'l' ? lo : (lo + hi) / 2; }; pin = lv(e[0]); pcomp = lv(e[1]); pout = lv(e[2]); pcnt = lv(e[3]); }
+        TRYD(hipStreamCreateWithPriority(&p->st_in, hipStreamNonBlocking, pin));
+        TRYD(hipStreamCreateWithPriority(&p->st_comp, hipStreamNonBlocking, pcomp));
+        TRYD(hipStreamCreateWithPriority(&p->st_out, hipStreamNonBlocking, pout));
+        TRYD(hipStreamCreateWithPriority(&p->st_cnt, hipStreamNonBlocking, pcnt));
     }
 #undef TRYD
     *out = p;
@@ -233,9 +247,10 @@ static int try_queue_output(basal_pipe *p, Slot &s, bool wait) {
             HIP_TRYQ(hipHostMalloc(&s.h_out, s.h_out_cap, hipHostMallocDefault));
         }
         s.out_bytes = cn.out_bytes;
-        if (s.out_bytes) HIP_TRYQ(hipMemcpyAsync(s.h_out, s.d.out, s.out_bytes, hipMemcpyDeviceToHost, s.st));
+        HIP_TRYQ(hipEventRecord(s.ev[EV_OUT0], p->st_out));
+        if (s.out_bytes) HIP_TRYQ(hipMemcpyAsync(s.h_out, s.d.out, s.out_bytes, hipMemcpyDeviceToHost, p->st_out));
     }
-    HIP_TRYQ(hipEventRecord(s.ev[EV_OUT], s.st));
+    HIP_TRYQ(hipEventRecord(s.ev[EV_OUT], p->st_out));
     s.out_queued = true;
     return BASAL_OK;
 }
@@ -249,7 +264,7 @@ static int queue_align(basal_pipe *p, Slot &s) {
         basal_align_extra ex;
         ex.counter = d.counter;
         ex.scratch = d.scratch;
-        return basal_launch_align(c, d.text, s.nbytes, d.raw, s.n_host, nullptr, 0, s.max_len, BASAL_STREAM_NONE, d.results, nullptr, 0, &d.cnt->stream_used, s.st, &ex);
+        return basal_launch_align(c, d.text, s.nbytes, d.raw, s.n_host, nullptr, 0, s.max_len, BASAL_STREAM_NONE, d.results, nullptr, 0, &d.cnt->stream_used, p->st_comp, &ex);
     }
     static const uint32_t cls_len[3] = {128, 256, BASAL_MAXREADLEN};
     for (int cl = 0; cl < 3; cl++) {
@@ -260,7 +275,7 @@ static int queue_align(basal_pipe *p, Slot &s) {
         ex.ghost_base = mr;
         ex.counter = d.counter;
         ex.scratch = d.scratch;
-        int rc = basal_launch_align(c, d.text, d.text_cap + 1024, d.desc, mr, d.stales, mr, cls_len[cl], smode, d.results, d.stream, d.stream_cap, &d.cnt->stream_used, s.st, &ex);
+        int rc = basal_launch_align(c, d.text, d.text_cap + 1024, d.desc, mr, d.stales, mr, cls_len[cl], smode, d.results, d.stream, d.stream_cap, &d.cnt->stream_used, p->st_comp, &ex);
         if (rc) return rc;
     }
     return BASAL_OK;
@@ -305,39 +320,44 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     s.batch_no = bno;
 #define TRYS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return fail(BASAL_EDEVICE); } } while (0)
 #define TRYR(x) do { int r_ = (x); if (r_) return fail(r_); } while (0)
-    TRYS(hipEventRecord(s.ev[EV_START], s.st));
-    TRYS(hipMemsetAsync(d.cnt, 0, sizeof(BatchCounters), s.st));
-    if (nbytes) TRYS(hipMemcpyAsync(d.text, s.h_blob, nbytes, hipMemcpyHostToDevice, s.st));
-    if (mode == MODE_RECORDS && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_rawread), hipMemcpyHostToDevice, s.st));
-    if (mode == MODE_PREPARED && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s.st));
-    TRYS(hipEventRecord(s.ev[EV_H2D], s.st));
+    // copies in
+    TRYS(hipEventRecord(s.ev[EV_START], p->st_in));
+    if (nbytes) TRYS(hipMemcpyAsync(d.text, s.h_blob, nbytes, hipMemcpyHostToDevice, p->st_in));
+    if (mode == MODE_RECORDS && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_rawread), hipMemcpyHostToDevice, p->st_in));
+    if (mode == MODE_PREPARED && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, p->st_in));
+    TRYS(hipEventRecord(s.ev[EV_H2D], p->st_in));
+    // kernels (this stream also keeps the batches' carry states in order)
+    TRYS(hipStreamWaitEvent(p->st_comp, s.ev[EV_H2D], 0));
+    TRYS(hipEventRecord(s.ev[EV_COMP0], p->st_comp));
+    TRYS(hipMemsetAsync(d.cnt, 0, sizeof(BatchCounters), p->st_comp));
     if (mode != MODE_PREPARED) {
-        if (p->last_prep_done) TRYS(hipStreamWaitEvent(s.st, p->last_prep_done, 0));  // the carry state of the batch before this one
-        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, p->sh, bno, nbytes, format, first_index, p->read_end, readset, mr, s.st));
-        else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, s.st));
-        TRYR(prep_enqueue_filter(c, p->k, d, p->sh, bno, mr, true, 0, s.st));
-        TRYS(hipEventRecord(s.prep_done, s.st));
+        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, p->sh, bno, nbytes, format, first_index, p->read_end, readset, mr, p->st_comp));
+        else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, p->st_comp));
+        TRYR(prep_enqueue_filter(c, p->k, d, p->sh, bno, mr, true, 0, p->st_comp));
     }
-    TRYS(hipEventRecord(s.ev[EV_PREP], s.st));
+    TRYS(hipEventRecord(s.ev[EV_PREP], p->st_comp));
     TRYR(queue_align(p, s));
-    TRYS(hipEventRecord(s.ev[EV_ALIGN], s.st));
-    if (mode != MODE_PREPARED) TRYR(prep_enqueue_format(c, p->k, d, p->sh, mr, s.st));
-    TRYS(hipEventRecord(s.ev[EV_FORMAT], s.st));
-    TRYS(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.st));
-    TRYS(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, s.st));
-    TRYS(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), s.st));
+    TRYS(hipEventRecord(s.ev[EV_ALIGN], p->st_comp));
+    if (mode != MODE_PREPARED) TRYR(prep_enqueue_format(c, p->k, d, p->sh, mr, p->st_comp));
+    TRYS(hipEventRecord(s.ev[EV_FORMAT], p->st_comp));
+    // copies out: the counters (and the guard ledger) always; the output itself once its size is known
+    TRYS(hipStreamWaitEvent(p->st_cnt, s.ev[EV_FORMAT], 0));
+    TRYS(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, p->st_cnt));
+    TRYS(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, p->st_cnt));
+    TRYS(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), p->st_cnt));
+    TRYS(hipEventRecord(s.ev[EV_COUNTERS], p->st_cnt));
     if (mode == MODE_PREPARED) {  // the size of the output is known: queue its copy right behind the kernel
-        if (n) TRYS(hipMemcpyAsync(s.h_out, d.results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, s.st));
+        TRYS(hipStreamWaitEvent(p->st_out, s.ev[EV_FORMAT], 0));
+        TRYS(hipEventRecord(s.ev[EV_OUT0], p->st_out));
+        if (n) TRYS(hipMemcpyAsync(s.h_out, d.results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, p->st_out));
         s.out_bytes = (uint64_t)n * sizeof(basal_result);
-        TRYS(hipEventRecord(s.ev[EV_COUNTERS], s.st));
-        TRYS(hipEventRecord(s.ev[EV_OUT], s.st));
+        TRYS(hipEventRecord(s.ev[EV_OUT], p->st_out));
         s.out_queued = true;
-    } else TRYS(hipEventRecord(s.ev[EV_COUNTERS], s.st));
+    }
 #undef TRYS
 #undef TRYR
     {
         std::lock_guard<std::mutex> lk(p->m);
-        if (mode != MODE_PREPARED) p->last_prep_done = s.prep_done;
         s.state = ST_INFLIGHT;
         p->inflight.push_back(si);
         p->acquired = -1;
@@ -397,15 +417,17 @@ extern "C" int basal_pipe_rewind(basal_pipe_t *p) {
     if (!p) { set_error("pipe_rewind: null argument"); return BASAL_EINVAL; }
     std::lock_guard<std::mutex> lk(p->m);
     HIP_TRYQ(hipSetDevice(p->c->device));
+    HIP_TRYQ(hipStreamSynchronize(p->st_in));
+    HIP_TRYQ(hipStreamSynchronize(p->st_comp));
+    HIP_TRYQ(hipStreamSynchronize(p->st_out));
+    HIP_TRYQ(hipStreamSynchronize(p->st_cnt));
     for (auto &s : p->slots) {
-        HIP_TRYQ(hipStreamSynchronize(s.st));
         s.state = ST_FREE;
         s.collecting = false;
     }
     p->inflight.clear();
     p->acquired = p->held = -1;
     if (p->broken) p->next_batch = p->rewind_to;
-    p->last_prep_done = nullptr;
     p->broken = false;
     p->cv.notify_all();
     return BASAL_OK;
@@ -455,7 +477,8 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             const BatchCounters &cn = *s.h_cnt;
             const bool stream_small = d.stream && cn.stream_used > d.stream_cap, out_small = cn.out_bytes > d.out_cap;
             if (!stream_small && !out_small && !(cn.irregular & 2u)) break;
-            HIP_TRYQ(hipStreamSynchronize(s.st));
+            HIP_TRYQ(hipStreamSynchronize(p->st_comp));
+            HIP_TRYQ(hipStreamSynchronize(p->st_cnt));
             if (stream_small || (cn.irregular & 2u)) {
                 hipFree(d.stream);
                 d.stream = nullptr;
@@ -472,15 +495,14 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             BatchCounters z = cn;
             z.n_aligned = z.n_unique = z.n_multiple = 0; z.out_bytes = 0; z.irregular &= ~2u;
             if (stream_small || (cn.irregular & 2u)) z.stream_used = 0;
-            HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, s.st));
-            HIP_TRYQ(hipStreamSynchronize(s.st));
+            HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, p->st_comp));
+            HIP_TRYQ(hipStreamSynchronize(p->st_comp));
             if (stream_small || (cn.irregular & 2u)) { int rc = queue_align(p, s); if (rc) return rc; }
-            { int rc = prep_enqueue_format(c, p->k, d, p->sh, p->o.max_reads, s.st); if (rc) return rc; }
-            HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.st));
-            HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, s.st));
-            HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), s.st));
-            HIP_TRYQ(hipEventRecord(s.ev[EV_COUNTERS], s.st));
-            HIP_TRYQ(hipEventSynchronize(s.ev[EV_COUNTERS]));
+            { int rc = prep_enqueue_format(c, p->k, d, p->sh, p->o.max_reads, p->st_comp); if (rc) return rc; }
+            HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, p->st_comp));
+            HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, p->st_comp));
+            HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), p->st_comp));
+            HIP_TRYQ(hipStreamSynchronize(p->st_comp));
             if ((ret = basal_report_guard(s.h_guard))) break;
         }
     }
@@ -497,10 +519,10 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
         stats->n_aligned = cn.n_aligned; stats->n_unique = cn.n_unique; stats->n_multiple = cn.n_multiple; stats->n_filtered = cn.n_filtered;
         if (!ret) {
             hipEventElapsedTime(&stats->ms_h2d, s.ev[EV_START], s.ev[EV_H2D]);
-            hipEventElapsedTime(&stats->ms_prep, s.ev[EV_H2D], s.ev[EV_PREP]);
+            hipEventElapsedTime(&stats->ms_prep, s.ev[EV_COMP0], s.ev[EV_PREP]);
             hipEventElapsedTime(&stats->ms_align, s.ev[EV_PREP], s.ev[EV_ALIGN]);
             hipEventElapsedTime(&stats->ms_format, s.ev[EV_ALIGN], s.ev[EV_FORMAT]);
-            hipEventElapsedTime(&stats->ms_d2h, s.ev[EV_COUNTERS], s.ev[EV_OUT]);
+            hipEventElapsedTime(&stats->ms_d2h, s.ev[EV_OUT0], s.ev[EV_OUT]);
         }
     }
     {

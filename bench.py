@@ -4,7 +4,9 @@
 Workload (BASELINE.json config 2): synthetic 100 bp SE reads, -M C:T, -g 0, -S 1, on an
 hg38-sized stand-in genome (tools/synth_gpu.py; hg38 itself is not on the GPU box), reference and
 seed index resident in HBM.  A "step" is ONE call of basal_core_align_batch_device on one batch
-of reads that is already in HBM (descriptors + bases in, 32-byte results out, results stay in HBM);
+of reads that is already in HBM (descriptors + bases in), plus the copy of that step's 32-byte results
+to page-locked host memory on a second stream, overlapped with the next step's kernel (the timed
+region ends when the last hit record is on the host, SURVEY.md section 8d);
 the default batch is config 2's whole 10 M reads (a launch has a fixed cost of about 1.4 ms -- reads
 from repeats take milliseconds and whichever starts last ends the launch -- so batches of millions
 are how the path is meant to be fed; --batch 1000000 reproduces the 1 M-read launches of DESIGN.md's ladder).
@@ -61,6 +63,60 @@ def spawn_ranks(n):
     return subprocess.run(cmd).returncode
 
 
+def time_reference(params_flags, rule, gap, read_len, n_reads, cores, dev):
+    """The TRUE reference binary (oracle/_ref/basal, built from /root/reference by oracle/Makefile.ref and shipped with the snapshot)
+    timed on this box's host cores.  It only reads files and rebuilds its index on every run, and an hg38-sized FASTA would take it
+    many minutes, so it runs on a density-equivalent down-scaled genome: 50 Mbp with -s 12 gives the 3-letter seeds the ~40 index
+    entries per seed that 3.09 Gbp gives them at -s 16.  Align time = wall clock minus
+    the wall clock of the same command with -E 0 (no reads: load + index build only).  Returns a cpu_baseline dict or None."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "basal")
+    if not os.path.exists(ref_bin) or n_reads <= 0:
+        return None
+    import basal_amd as B
+    import synth_files
+    import synth_gpu
+    import torch
+    d = tempfile.mkdtemp(prefix="basal_ref_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        p = B.Params(rule, ["-M", rule])
+        G = synth_gpu.make_genome(p, dev, scale=50e6 / 3.088e9, seed=7, repeat_copies=650)
+        fa, fq = os.path.join(d, "g.fa"), os.path.join(d, "r.fq")
+        synth_files.write_fasta(fa, G)
+        frm = "ACGT".index(rule[0])
+        tos = [t for t in rule[2:] if t in "ACGT"]
+        to = "ACGT".index(tos[0]) if tos else frm
+        with open(fq, "wb") as f:
+            for b0 in range(0, n_reads, 400_000):
+                nb = min(400_000, n_reads - b0)
+                bases, _, _, _ = synth_gpu.make_reads(G, nb, dev, read_len=read_len, seed=500 + b0, conv_from=frm, conv_to=to, p_conv=0.95 if tos else 0.0)
+                f.write(synth_files.fastq_bytes(bases.cpu().numpy().reshape(nb, read_len), np.full(nb, read_len), None, first=b0))
+        del G
+        torch.cuda.empty_cache()
+        cmd = [ref_bin, "-a", fq, "-d", fa, "-M", rule, "-S", "1", "-s", "12", "-p", str(cores), "-o", os.path.join(d, "o.sam")] + (["-g", str(gap)] if gap else [])
+
+        def wall(extra):
+            t = time.perf_counter()
+            r = subprocess.run(cmd + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                raise RuntimeError("reference binary failed")
+            return time.perf_counter() - t
+        t_idle = min(wall(["-E", "0"]) for _ in range(2))
+        t_full = min(wall([]) for _ in range(2))
+        secs = max(t_full - t_idle, 1e-3)
+        return {"value": n_reads / secs / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
+                "sample": "the unmodified reference binary (oracle/_ref/basal -p %d) on %d reads of the same kind on a density-equivalent down-scaled genome "
+                          "(50 Mbp, -s 12: ~40 index entries per seed as on 3.09 Gbp at -s 16); align time = wall %.2f s minus %.2f s of the same command with -E 0 "
+                          "(load + index build); %.0f CPU-seconds of alignment" % (cores, n_reads, t_full, t_idle, secs * cores)}
+    except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
+        log("reference timing failed: %r" % (e,))
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +126,7 @@ def main():
     ap.add_argument("--genome-scale", type=float, default=float(os.environ.get("BASAL_BENCH_SCALE", "1.0")), help="1.0 = hg38-sized (3.09 Gbp)")
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads of the cpu_baseline / parity sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--ref-sample", type=int, default=1_600_000, help="reads the true reference binary is timed on (0 = skip; it is skipped when oracle/_ref/basal is missing)")
     ap.add_argument("--rule", default="C:T")
     ap.add_argument("--gap", type=int, default=0)
     ap.add_argument("--read-len", type=int, default=100, help="read length (the headline workload is 100; 150/300 exercise the 256/480-base kernels)")
@@ -169,13 +226,28 @@ def main():
     d_used = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     core.set_timing(True)
+    # every step's records go to page-locked host memory (one buffer per pool slot), copied on a second stream behind the kernel
+    h_results = torch.empty(n_reads * 32, dtype=torch.uint8, pin_memory=True)
+    # (a stream of another priority: HIP multiplexes streams onto a few hardware queues, and two streams that land on the same queue
+    # run in submission order -- the copies would then wait for kernels queued before them instead of overlapping them)
+    copy_stream = torch.cuda.Stream(dev, priority=-1)
+    copied = {}  # step -> event behind its copy (a pool slot is not rewritten before its last copy has left)
 
     def step(i):
         j = i % n_pool
+        if i - n_pool in copied:
+            torch.cuda.current_stream(dev).wait_event(copied.pop(i - n_pool))
         rc = L.basal_core_align_batch_device(core.h, d_bases.data_ptr() + j * args.batch * read_len, d_reads.data_ptr() + j * args.batch * 16, args.batch, None, 0,
                                              B.STREAM_NONE, d_results.data_ptr() + j * args.batch * 32, None, 0, d_used.data_ptr(), None,
                                              read_len, stream)
         bc._check(rc, "align_batch_device")
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ev)
+            h_results[j * args.batch * 32:(j + 1) * args.batch * 32].copy_(d_results[j * args.batch * 32:(j + 1) * args.batch * 32], non_blocking=True)
+            copied[i] = torch.cuda.Event()
+            copied[i].record(copy_stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -235,6 +307,8 @@ def main():
     unique = int((has & (nh == 1)).sum().item())
     n_timed = int(rv.shape[0])
     timed = np.frombuffer(d_results[first_slot * step_bytes:(first_slot + 1) * step_bytes].cpu().numpy().tobytes(), dtype=bc.RESULT_DTYPE)
+    if n_steps <= n_pool:  # what arrived on the host is what the device holds (slots not overwritten by later steps)
+        assert h_results[first_slot * step_bytes:(first_slot + 1) * step_bytes].numpy().tobytes() == timed.tobytes(), "host copy of the results differs"
     del rv, has, nh
     blocks_, threads_, lds_ = core.launch_info()
 
@@ -244,7 +318,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": "config 2: %d M synthetic %d bp SE reads per GPU (%d per step), -M %s -g %d -S 1, hg38-sized synthetic genome "
-                               "(%.2f Gbp, %d contigs, N gaps, planted repeats), reference + seed index resident in HBM, reads resident in HBM"
+                               "(%.2f Gbp, %d contigs, N gaps, planted repeats), reference + seed index resident in HBM, reads resident in HBM, every step's hit records copied to page-locked host memory inside the timed region"
                                % (args.batch * args.steps // 1_000_000, args.read_len, args.batch, args.rule, args.gap, total_bp / 1e9, len(sizes)),
                    "reads_per_step_per_gpu": args.batch, "genome_bp": total_bp, "index_entries": None, "aligned_frac": aligned / max(1, n_timed),
                    "unique_frac": unique / max(1, n_timed), "gathered_aligned_reads": gathered_aligned, "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
@@ -301,16 +375,52 @@ def main():
         t = json.load(open(tj))
         roof["traffic"] = t["hbm_bytes_per_read"] * args.batch
         roof["traffic_source"] = t["source"]
-    # PCIe-inclusive rate (host buffers in, host buffers out) -- reported next to value, never as value
-    if rank == 0 and world == 1:
+    # Host-to-host rate: prepared reads in page-locked host buffers -> H2D -> kernel -> D2H of the hit records, three batches in
+    # flight on their own streams (basal_pipe_*, BASAL_PIPE_OUT_RESULTS). Reported next to value, never as value.
+    if rank == 0 and world == 1 and not os.environ.get("BASAL_BENCH_NO_H2H"):
+        torch.cuda.synchronize()
         hb = d_bases[: args.batch * read_len].cpu().numpy()
         hd = descs[: args.batch].copy()
-        core.align_batch(hb, hd)  # warm the staging buffers
+        pipe = B.Pipe(core, depth=3, max_reads=args.batch, max_bytes=args.batch * read_len + 4096, output=B.PIPE_OUT_RESULTS)
+        for _ in range(3):  # fill the three slots' page-locked buffers once (the caller's reads; this also faults their pages in), untimed
+            bl, rw = pipe.acquire()
+            bl[: len(hb)] = hb
+            rw[: hd.nbytes] = hd.view(np.uint8).reshape(-1)
+            bc._check(L.basal_pipe_submit_prepared(pipe.h, len(hb), len(hd), read_len), "pipe_submit_prepared")
+        for _ in range(3):
+            rc, data, _st = pipe.collect(copy=False)
+            assert rc == 0, data
+            pipe.release()
+        nb_h2h, inflight, submitted, collected = 6, 0, 0, 0
+        got = None
         t1 = time.perf_counter()
-        for _ in range(2):
-            core.align_batch(hb, hd)
-        out["config"]["pcie_inclusive_mreads_per_s"] = round(2 * args.batch / (time.perf_counter() - t1) / 1e6, 2)
+        while collected < nb_h2h:
+            while inflight < 3 and submitted < nb_h2h:
+                pipe.acquire()
+                bc._check(L.basal_pipe_submit_prepared(pipe.h, len(hb), len(hd), read_len), "pipe_submit_prepared")
+                inflight += 1
+                submitted += 1
+            rc, data, _st = pipe.collect(copy=False)
+            assert rc == 0, data
+            if got is None:
+                got = C.string_at(data[0], 32 * min(args.batch, 100000))
+            pipe.release()
+            inflight -= 1
+            collected += 1
+        dt_h2h = time.perf_counter() - t1
+        out["config"]["host_to_host_mreads_per_s"] = round(nb_h2h * args.batch / dt_h2h / 1e6, 2)
+        out["config"]["host_to_host_note"] = ("prepared reads (bases + 16-byte descriptors, %d B/read) in page-locked host buffers -> HBM -> kernel -> %d B/read of hit records in "
+                                              "page-locked host memory; %d batches of %d reads, 3 in flight (basal_pipe_*)" % (read_len + 16, 32, nb_h2h, args.batch))
+        assert got == d_results[: len(got)].cpu().numpy().tobytes(), "host-to-host results differ from the resident run"
+        pipe.close()
+        del pipe
     out["roofline"] = roof
+    if rank == 0 and world == 1 and cpu is not None and args.ref_sample > 0:
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        ref_cpu = time_reference(flags, args.rule, args.gap, read_len, args.ref_sample, threads, dev)
+        if ref_cpu is not None:  # the reference itself is the baseline; the port on the exact workload stays next to it
+            out["config"]["cpu_port"] = cpu
+            cpu = ref_cpu
     out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
