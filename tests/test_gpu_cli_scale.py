@@ -122,3 +122,37 @@ def test_cli_irregular_text_falls_back_to_host_parsing(tmp_path):
     assert "parsing it on the host" in r.stderr
     got = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+def test_cli_pe_200k_pairs_match_reference(tmp_path):
+    """BASELINE.json config 3's shape (150-base pairs, -M A:G) at 200 000 pairs on a transcriptome-like reference of many contigs:
+    the CLI (mates aligned on the GPU, pairing rounds on the host) against the reference binary, byte for byte."""
+    import torch
+    import synth_gpu
+    import synth_files
+    tmp = str(tmp_path)
+    dev = torch.device("cuda", 0)
+    p = B.Params("A:G", ["-M", "A:G"])
+    G = synth_gpu.make_genome(p, dev, scale=0.01, seed=61, repeat_copies=2000)
+    fa, f1, f2 = os.path.join(tmp, "g.fa"), os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+    synth_files.write_fasta(fa, G)
+    n, L = 200_000, 150
+    b1, b2 = synth_gpu.make_pairs(G, n, dev, read_len=L, seed=62)
+    s1, s2 = b1.cpu().numpy().reshape(n, L), b2.cpu().numpy().reshape(n, L)
+    d1, l1, q1 = synth_files.dirty(s1, 63, adapter_frac=0.0, lower_frac=0.0)
+    d2, l2, q2 = synth_files.dirty(s2, 64, adapter_frac=0.0, lower_frac=0.0)
+    open(f1, "wb").write(synth_files.fastq_bytes(d1, l1, q1, name_prefix=b"p"))
+    open(f2, "wb").write(synth_files.fastq_bytes(d2, l2, q2, name_prefix=b"p"))
+    del G
+    torch.cuda.empty_cache()
+    flags = ["-M", "A:G", "-S", "1", "-s", "12", "-u", "-x", "700"]
+    out, ref = os.path.join(tmp, "out.sam"), os.path.join(tmp, "ref.sam")
+    r = subprocess.run([BASAL_BIN, "-a", f1, "-b", f2, "-d", fa] + flags + ["-p", "16", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    checker = orc.REF_BIN if os.path.exists(orc.REF_BIN) else orc.CLI
+    # (relative paths: the reference's paired-end branch sprintf()s its command line into a 256-byte buffer, main.cpp:410,522)
+    c = subprocess.run([checker, "-a", "r1.fq", "-b", "r2.fq", "-d", "g.fa"] + flags + ["-p", "1", "-o", "ref.sam"], capture_output=True, text=True, cwd=tmp)
+    assert c.returncode == 0, c.stderr
+    got, want = sam_digest(out), sam_digest(ref)
+    assert got[1] == want[1] and got[1] >= 2 * n * 0.9
+    assert got[0] == want[0]

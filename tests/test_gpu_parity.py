@@ -227,3 +227,41 @@ def test_cli_bam_input(name, tmp_path):
     assert r.returncode == 0, r.stderr
     got = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+@pytest.mark.parametrize("name", ["ct_basic", "varlen_trim", "pe_ct_100_u"])
+def test_cli_sam_text_input(name, tmp_path):
+    """`-a reads.sam` with header-less SAM text (reads.cpp:84-110 means to take it; in the reference itself the path is dead:
+    ReadClass::InitIndex opens every SAM/BAM input with mode "rb", reads.cpp:34-36, so SAM text is read as BAM and yields no reads --
+    observed with oracle/_ref/basal).  The CLI parses what samtools' text reader would have delivered: the same reads as the FASTQ form."""
+    import sys
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    pe = H.MANIFEST[name]["pe"]
+    sam_in = str(tmp_path / "reads.sam")
+    subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "fq2sam.py"), fq, sam_in] + ([fq2] if pe else []), check=True)
+    out = tmp_path / "o.sam"
+    r = subprocess.run([BASAL_BIN, "-a", sam_in] + (["-b", sam_in] if pe else []) + ["-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "4", "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)
+
+
+@pytest.mark.parametrize("name", ["ct_basic", "tdel_pipeline", "pe_ct_100_u"])
+def test_cli_bam_output(name, tmp_path):
+    """`-o x.bam` pipes the SAM text through an external `samtools view -bS -` like the reference (main.cpp:504-513). The box has no
+    samtools of its own; oracle/_ref/samtools (the reference's vendored 0.1.18, built by oracle/Makefile.ref) is put on PATH."""
+    st = os.path.join(H.ROOT, "oracle", "_ref", "samtools")
+    if not os.path.exists(st):
+        pytest.skip("no samtools binary (oracle/_ref/samtools is built where /root/reference is mounted)")
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    pe = H.MANIFEST[name]["pe"]
+    out = str(tmp_path / "o.bam")
+    env = dict(os.environ, PATH=os.path.dirname(st) + os.pathsep + os.environ.get("PATH", ""))
+    r = subprocess.run([BASAL_BIN, "-a", fq] + (["-b", fq2] if pe else []) + ["-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "4", "-o", out],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    v = subprocess.run([st, "view", "-h", out], capture_output=True, text=True)
+    assert v.returncode == 0, v.stderr
+    got = "".join(l + "\n" for l in v.stdout.splitlines() if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)

@@ -132,3 +132,99 @@ def test_full_size_properties():
     assert ((res["best"]["chr"] & 1) == rev)[uniq & ok].all()
     assert run(core, hb, descs, split=333_333).tobytes() == res.tobytes()
     assert run(core, hb, descs).tobytes() == res.tobytes()
+
+
+def _host_ref_from_genome(p, G, tmp):
+    """The product's host-side reference object (FASTA loader) for a generated genome."""
+    import synth_files
+    fa = os.path.join(tmp, "g.fa")
+    synth_files.write_fasta(fa, G)
+    return B.Reference(p, fasta_path=fa)
+
+
+def test_gpu_index_build_matches_host_build_at_500mbp(tmp_path):
+    """basal_core_build_index against basal_host_ref_build_index on a 500 Mbp genome with N gaps (250 M index entries): every array
+    equal.  The at-scale parity tests hand the oracle the GPU-built index, so this is what ties that index to the CPU build (which
+    tests/test_host_parity.py ties to the oracle's own)."""
+    import torch
+    import synth_gpu
+    dev = torch.device("cuda", 0)
+    p = B.Params("C:T", ["-M", "C:T", "-S", "1"])
+    G = synth_gpu.make_genome(p, dev, scale=500e6 / 3.088e9, seed=9, repeat_copies=6000)
+    ref = _host_ref_from_genome(p, G, str(tmp_path))
+    # the FASTA loader's packed words equal the generator's (two independent packers)
+    for s in range(2):
+        assert np.array_equal(ref.words(s), G.words[s].cpu().numpy().view(np.uint64))
+    del G
+    torch.cuda.empty_cache()
+    ref.build_index(16)
+    off, nfwd, locs, mk = ref.index()
+    assert len(locs) > 240_000_000
+    core = B.Core(p)
+    mk_gpu = core.upload(ref, build_on_gpu=True)
+    goff, gnfwd, glocs, gmk = core.get_index(len(nfwd))
+    assert mk_gpu == mk == gmk
+    assert np.array_equal(goff, off)
+    assert np.array_equal(gnfwd, nfwd)
+    assert np.array_equal(glocs, locs)
+
+
+def test_gpu_index_build_beyond_2_31_entries():
+    """An hg38-sized genome at -I 2 has 3.09 G index entries: more than a signed 32-bit count (the sort and the scan take 64-bit item
+    counts) and less than the 2^32 - 1 the reference's own 32-bit counters allow.  Too large for a CPU build inside a test: the CSR
+    invariants carry it.  -I 1 (6.2 G entries) must be refused with an error, not wrapped."""
+    import torch
+    import synth_gpu
+    dev = torch.device("cuda", 0)
+    p = B.Params("C:T", ["-M", "C:T", "-S", "1", "-I", "2"])
+    G = synth_gpu.make_genome(p, dev, scale=1.0, seed=1)
+    words = [w.cpu().numpy().view(np.uint64) for w in G.words]
+    sizes = np.array(G.sizes, dtype=np.uint32)
+    blocks = np.ascontiguousarray(G.blocks)
+    anchors, rco = G.anchors, G.rc_offsets
+    del G
+    torch.cuda.empty_cache()
+    L = B.lib()
+
+    def stage(params):
+        core = B.Core(params, 0)
+        bc._check(L.basal_core_set_reference(core.h, words[0].ctypes.data, words[1].ctypes.data, len(words[0]), anchors.ctypes.data, sizes.ctypes.data,
+                                             rco.ctypes.data, len(sizes)), "set_reference")
+        mk = C.c_uint32()
+        return core, L.basal_core_build_index(core.h, blocks.ctypes.data, len(blocks), C.byref(mk)), mk.value
+    core, rc, mk = stage(p)
+    assert rc == 0, L.basal_last_error()
+    # expected entry count from the blocks (refbase.cpp:303-325): positions i0, i0+I, ... <= (end-k)/I*I per block
+    K, I = 16, 2
+    i0 = (blocks[:, 1].astype(np.int64) // I) * I
+    i2 = ((blocks[:, 2].astype(np.int64) - K) // I) * I
+    ok = (blocks[:, 2] >= K) & (i2 >= i0)
+    expect = int(((i2[ok] - i0[ok]) // I + 1).sum())
+    assert 2 ** 31 < expect < 2 ** 32 - 1
+    tk = 3 ** 16
+    n = C.c_uint64()
+    mk2 = C.c_uint32()
+    bc._check(L.basal_core_get_index(core.h, None, None, None, C.byref(n), C.byref(mk2)), "get_index")
+    assert n.value == expect
+    off = np.zeros(tk + 1, np.uint32)
+    nf = np.zeros(tk, np.uint32)
+    bc._check(L.basal_core_get_index(core.h, off.ctypes.data, nf.ctypes.data, None, C.byref(n), C.byref(mk2)), "get_index")
+    cnt = np.diff(off.astype(np.int64))
+    assert off[0] == 0 and off[tk] == expect and (cnt >= 0).all() and (nf.astype(np.int64) <= cnt).all()
+    assert mk2.value == mk and mk > 0
+    # the locations of a few thousand k-mers: forward entries ascending, then reverse-complement entries ascending, all even (I = 2)
+    import torch as T
+    core_locs = None
+    locs = np.zeros(expect, np.uint32)
+    bc._check(L.basal_core_get_index(core.h, None, None, locs.ctypes.data, C.byref(n), C.byref(mk2)), "get_index")
+    assert (locs % 2 == 0).all()
+    rng = np.random.default_rng(4)
+    for k in rng.integers(0, tk, 4000):
+        a, b, f = int(off[k]), int(off[k + 1]), int(nf[k])
+        seg = locs[a:b].astype(np.int64)
+        assert (np.diff(seg[:f]) > 0).all() and (np.diff(seg[f:]) > 0).all()
+    del core, locs
+    # -I 1: 6.2 G entries do not fit the 32-bit offsets: refused
+    p1 = B.Params("C:T", ["-M", "C:T", "-S", "1", "-I", "1"])
+    core1, rc1, _ = stage(p1)
+    assert rc1 == -1 and b"2^32" in L.basal_last_error()

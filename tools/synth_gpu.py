@@ -144,3 +144,47 @@ def make_reads(G, n, device, read_len=100, seed=2, p_conv=0.95, sub_rate=0.01, r
     ascii_t = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
     bases = ascii_t[out.long()].reshape(-1).contiguous()
     return bases, seg_ci, start, rev
+
+
+def make_pairs(G, n, device, read_len=150, frag_min=200, frag_max=600, seed=3, p_conv=0.9, sub_rate=0.01, rev_frac=0.5, conv_from=0, conv_to=2):
+    """n read pairs (two n*read_len uint8 ASCII tensors): fragments of frag_min..frag_max bases, mate 1 = the fragment's first read_len
+    bases, mate 2 = the reverse complement of its last read_len bases; the conversion acts on the fragment's mate-1 strand, so mate 2
+    shows its complement."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    segs = []
+    for ci, runs in enumerate(G.nmask_runs):
+        prev = 0
+        for a, b in runs + [(G.sizes[ci], G.sizes[ci])]:
+            if a - prev > frag_max + 1:
+                segs.append((ci, prev, a - frag_max))
+            prev = b
+    seg_len = torch.tensor([e - s for _, s, e in segs], dtype=torch.float64)
+    pick = torch.multinomial(seg_len / seg_len.sum(), n, replacement=True, generator=torch.Generator().manual_seed(seed)).to(device)
+    seg_ci = torch.tensor([c for c, _, _ in segs], device=device)[pick]
+    seg_s = torch.tensor([s for _, s, _ in segs], device=device, dtype=torch.int64)[pick]
+    seg_e = torch.tensor([e for _, _, e in segs], device=device, dtype=torch.int64)[pick]
+    start = seg_s + (torch.rand(n, generator=g, device=device, dtype=torch.float64) * (seg_e - seg_s).double()).long()
+    flen = frag_min + (torch.rand(n, generator=g, device=device) * (frag_max - frag_min + 1)).long().clamp(max=frag_max - frag_min)
+    flen = torch.maximum(flen, torch.full_like(flen, read_len))
+    a_ = torch.empty((n, read_len), dtype=torch.uint8, device=device)
+    b_ = torch.empty((n, read_len), dtype=torch.uint8, device=device)
+    ar = torch.arange(read_len, device=device)
+    for ci in range(len(G.sizes)):
+        m = (seg_ci == ci).nonzero(as_tuple=True)[0]
+        if m.numel() == 0:
+            continue
+        a_[m] = G.ids[ci][start[m][:, None] + ar[None, :]]
+        b_[m] = 3 - G.ids[ci][(start[m] + flen[m] - 1)[:, None] - ar[None, :]]
+    rev = torch.rand(n, generator=g, device=device) < rev_frac
+    r1 = torch.where(rev[:, None], b_, a_)
+    r2 = torch.where(rev[:, None], a_, b_)
+    c1 = (r1 == conv_from) & (torch.rand(r1.shape, generator=g, device=device) < p_conv)
+    r1 = torch.where(c1, torch.full_like(r1, conv_to), r1)
+    c2 = (r2 == 3 - conv_from) & (torch.rand(r2.shape, generator=g, device=device) < p_conv)
+    r2 = torch.where(c2, torch.full_like(r2, 3 - conv_to), r2)
+    for r in (r1, r2):
+        sub = torch.rand(r.shape, generator=g, device=device) < sub_rate
+        r[sub] = ((r + torch.randint(1, 4, r.shape, generator=g, device=device, dtype=torch.uint8)) % 4)[sub]
+    ascii_t = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    return ascii_t[r1.long()].reshape(-1).contiguous(), ascii_t[r2.long()].reshape(-1).contiguous()
