@@ -265,3 +265,27 @@ def test_cli_bam_output(name, tmp_path):
     assert v.returncode == 0, v.stderr
     got = "".join(l + "\n" for l in v.stdout.splitlines() if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+REF_GPU_BIN = os.path.join(H.ROOT, "oracle", "_ref_gpu", "basal")
+
+
+@pytest.mark.parametrize("name", ["c1_s16", "ct_basic", "ct_n1_dirty", "ag_se", "acgt_g2", "tdel_pipeline", "gact_del", "ct_g3", "rep_r2_w10", "rep_r0_u",
+                                  "varlen_trim", "varlen_s16", "tx_ag_150", "long_490_g1", "I16_g1", "edge_Nmis", "fa_reads", "contigs_5k"])
+def test_reference_host_on_gpu_core(name, tmp_path):
+    """The north star's arrangement as a binary: the UNMODIFIED reference host (its main.cpp, reads.cpp, refbase.cpp, param.cpp, its
+    FilterReads and s_OutHit, its own 2-bit reference and seed index) with SingleAlign::Do_Batch from integration/do_batch_gpu.inc on
+    libbasal_amd.so (tools/build_ref_with_core.sh; built where /root/reference is mounted, shipped with the snapshot).  Its SAM must be
+    the golden SAM the pure-CPU reference printed."""
+    if not os.path.exists(REF_GPU_BIN):
+        pytest.skip("oracle/_ref_gpu/basal not built (tools/build_ref_with_core.sh needs /root/reference)")
+    import gzip
+    fa, fq, _, _ = H.fixture_paths(name)
+    # (the reference reads .gz through its own gzstream; plain copies keep its 256/1000-byte command-line buffers safe)
+    pf, pq = str(tmp_path / "g.fa"), str(tmp_path / "r.fq")
+    for src, dst in ((fa, pf), (fq, pq)):
+        open(dst, "wb").write(gzip.open(src, "rb").read() if src.endswith(".gz") else open(src, "rb").read())
+    r = subprocess.run([REF_GPU_BIN, "-a", "r.fq", "-d", "g.fa"] + H.MANIFEST[name]["flags"] + ["-p", "1", "-o", "o.sam"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    got = "".join(l for l in open(tmp_path / "o.sam") if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)
