@@ -1079,15 +1079,20 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         const SeedEntGap g = L.entg[eif];
                         uint32_t lc = cur.loc_raw - (e_hcs & 0xffffu);
                         if (((unsigned long long)(lc >> 5) + NWT + 4) >= COLD(nwords)) lc = (uint32_t)guard_idx(cx, G_XREF, lc, 0, r) + BASAL_REF_MARGIN * 32;
-                        const uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, cur.fb);
-                        const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e_fr, e_fc, cur.f) & e_fm) + XM64(db & g.bm);
-                        const bool al = lb <= st.thr, gk = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
+                        const uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, cur.fb), da = cmp_word<NEWRULE>(e_fr, e_fc, cur.f);
+                        const uint32_t lb = rc.n_count + XM64(da & e_fm) + XM64(db & g.bm);
+                        const bool al = lb <= st.thr;
+                        bool gk = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
                         keep = al || gk;
                         sv.loc = lc;
                         sv.meta = eif | ((uint32_t)(cur.jj >= e_nfwd) << 8) | ((uint32_t)al << 9) | ((uint32_t)gk << 10);
                     }
                     PH(PH_FILTER);
                     uint64_t mk = ballot(keep);
+#ifdef BASAL_PHASE_TIMING
+                    phc.n_chunks += (uint32_t)__popcll(ballot(af)); phc.n_alive += (uint32_t)__popcll(mk);
+                    phc.n_bigchunks += (uint32_t)__popcll(ballot(af && (sv.meta >> 9 & 1))); phc.n_bigalive += (uint32_t)__popcll(ballot(af && (sv.meta >> 10 & 1)));
+#endif
                     if (keep) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
                     nsurv += (uint32_t)__popcll(mk);
                     t0 += 64;

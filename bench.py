@@ -63,7 +63,7 @@ def spawn_ranks(n):
     return subprocess.run(cmd).returncode
 
 
-def time_reference(params_flags, rule, gap, read_len, n_reads, cores, dev):
+def time_reference(rule, gap, extra_flags, read_kw, read_len, n_reads, cores, dev):
     """The TRUE reference binary (oracle/_ref/basal, built from /root/reference by oracle/Makefile.ref and shipped with the snapshot)
     timed on this box's host cores.  It only reads files and rebuilds its index on every run, and an hg38-sized FASTA would take it
     many minutes, so it runs on a density-equivalent down-scaled genome: 50 Mbp with -s 12 gives the 3-letter seeds the ~40 index
@@ -85,17 +85,14 @@ def time_reference(params_flags, rule, gap, read_len, n_reads, cores, dev):
         G = synth_gpu.make_genome(p, dev, scale=50e6 / 3.088e9, seed=7, repeat_copies=650)
         fa, fq = os.path.join(d, "g.fa"), os.path.join(d, "r.fq")
         synth_files.write_fasta(fa, G)
-        frm = "ACGT".index(rule[0])
-        tos = [t for t in rule[2:] if t in "ACGT"]
-        to = "ACGT".index(tos[0]) if tos else frm
         with open(fq, "wb") as f:
             for b0 in range(0, n_reads, 400_000):
                 nb = min(400_000, n_reads - b0)
-                bases, _, _, _ = synth_gpu.make_reads(G, nb, dev, read_len=read_len, seed=500 + b0, conv_from=frm, conv_to=to, p_conv=0.95 if tos else 0.0)
+                bases, _, _, _ = synth_gpu.make_reads(G, nb, dev, read_len=read_len, seed=500 + b0, **read_kw)
                 f.write(synth_files.fastq_bytes(bases.cpu().numpy().reshape(nb, read_len), np.full(nb, read_len), None, first=b0))
         del G
         torch.cuda.empty_cache()
-        cmd = [ref_bin, "-a", fq, "-d", fa, "-M", rule, "-S", "1", "-s", "12", "-p", str(cores), "-o", os.path.join(d, "o.sam")] + (["-g", str(gap)] if gap else [])
+        cmd = [ref_bin, "-a", fq, "-d", fa, "-M", rule, "-S", "1", "-s", "12", "-p", str(cores), "-o", os.path.join(d, "o.sam")] + (["-g", str(gap)] if gap else []) + list(extra_flags)
 
         def wall(extra):
             t = time.perf_counter()
@@ -127,8 +124,16 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads of the cpu_baseline / parity sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--ref-sample", type=int, default=1_600_000, help="reads the true reference binary is timed on (0 = skip; it is skipped when oracle/_ref/basal is missing)")
-    ap.add_argument("--rule", default="C:T")
-    ap.add_argument("--gap", type=int, default=0)
+    ap.add_argument("--config", default="2", choices=["2", "4", "5", "5p"],
+                    help="BASELINE.json config whose reads and flags to use (SURVEY.md section 8d): 2 = C:T -g 0 (the bench line); 4 = A:CGT -g 2, each A to C/G/T "
+                         "with p 0.3, 1 %% of the reads with a 1-2 base indel; 5 = T:- (30 %% of the reads with one T deleted), -g 0; 5p = the same reads with the "
+                         "BID-seq pipeline flags -n 1 -g 3")
+    ap.add_argument("--rule", default=None, help="ad hoc: another -M rule with config 2's kind of reads")
+    ap.add_argument("--gap", type=int, default=None)
+    ap.add_argument("--genome", default="uniform", choices=["uniform", "realistic"],
+                    help="uniform: random bases + one planted 300-base family (the bench line's stand-in); realistic: a repeat landscape shaped like hg38's "
+                         "(Alu / L1 / MIR / L2 / LTR / DNA families + satellites, ~45 %% of the genome): the over-represented-k-mer cut-off then lands where "
+                         "seeds from repeats keep tens of thousands of candidates, as on the real genome")
     ap.add_argument("--read-len", type=int, default=100, help="read length (the headline workload is 100; 150/300 exercise the 256/480-base kernels)")
     args = ap.parse_args()
 
@@ -168,13 +173,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    flags = ["-M", args.rule, "-S", "1"] + (["-g", str(args.gap)] if args.gap else [])
+    presets = {"2": ("C:T", 0, []), "4": ("A:CGT", 2, []), "5": ("T:-", 0, []), "5p": ("T:-", 3, ["-n", "1"])}
+    p_rule, p_gap, p_extra = presets[args.config]
+    adhoc = args.rule is not None or args.gap is not None
+    args.rule = args.rule or p_rule
+    args.gap = p_gap if args.gap is None else args.gap
+    flags = ["-M", args.rule, "-S", "1"] + (["-g", str(args.gap)] if args.gap else []) + p_extra
     params = B.Params(args.rule, flags)
     L = B.lib()
 
     # ---- reference + index, staged once -----------------------------------------------------
     t0 = time.time()
-    G = synth_gpu.make_genome(params, dev, scale=args.genome_scale, seed=1, repeat_copies=int(os.environ.get("BASAL_BENCH_REPEAT_COPIES", "40000")))
+    G = synth_gpu.make_genome(params, dev, scale=args.genome_scale, seed=1, repeat_copies=int(os.environ.get("BASAL_BENCH_REPEAT_COPIES", "40000")),
+                              realistic=args.genome == "realistic")
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     words = [w.cpu().numpy().view(np.uint64) for w in G.words]
@@ -199,12 +210,16 @@ def main():
     n_reads = args.batch * n_pool
     read_len = args.read_len
     frm, to = "ACGT".index(args.rule[0].upper()), "ACGT".index(args.rule[2].upper()) if args.rule[2] in "ACGTacgt" else None
+    read_kw = dict(conv_from=frm, conv_to=to if to is not None else frm, p_conv=0.95 if to is not None else 0.0)
+    if not adhoc and args.config == "4":
+        read_kw = dict(conv_from=0, conv_to=[1, 2, 3], p_conv=0.3, indel_frac=0.01, indel_max=2)
+    elif not adhoc and args.config in ("5", "5p"):
+        read_kw = dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80)
     chunks = []
     per = 2_000_000
     for c0 in range(0, n_reads, per):
         nb = min(per, n_reads - c0)
-        b, _, _, _ = synth_gpu.make_reads(G, nb, dev, read_len=read_len, seed=1000 * (rank + 1) + c0 // per, conv_from=frm,
-                                          conv_to=to if to is not None else frm, p_conv=0.95 if to is not None else 0.0)
+        b, _, _, _ = synth_gpu.make_reads(G, nb, dev, read_len=read_len, seed=1000 * (rank + 1) + c0 // per, **read_kw)
         chunks.append(b)
     d_bases = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
     del chunks
@@ -317,15 +332,17 @@ def main():
         "value": reads_timed / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": "config 2: %d M synthetic %d bp SE reads per GPU (%d per step), -M %s -g %d -S 1, hg38-sized synthetic genome "
-                               "(%.2f Gbp, %d contigs, N gaps, planted repeats), reference + seed index resident in HBM, reads resident in HBM, every step's hit records copied to page-locked host memory inside the timed region"
-                               % (args.batch * args.steps // 1_000_000, args.read_len, args.batch, args.rule, args.gap, total_bp / 1e9, len(sizes)),
+        "config": {"workload": ("config %s: %d M synthetic %d bp SE reads per GPU (%d per step), -M %s -g %d -S 1%s, hg38-sized synthetic genome "
+                                "(%.2f Gbp, %d contigs, N gaps, " + ("hg38-like repeat landscape: ~45 %% repeats" if args.genome == "realistic" else "planted repeats") + "), reference + seed index resident in HBM, reads resident in HBM, every step's hit "
+                                "records copied to page-locked host memory inside the timed region")
+                               % (args.config, args.batch * args.steps // 1_000_000, args.read_len, args.batch, args.rule, args.gap, (" " + " ".join(p_extra)) if p_extra else "",
+                                  total_bp / 1e9, len(sizes)),
                    "reads_per_step_per_gpu": args.batch, "genome_bp": total_bp, "index_entries": None, "aligned_frac": aligned / max(1, n_timed),
                    "unique_frac": unique / max(1, n_timed), "gathered_aligned_reads": gathered_aligned, "kernel_grid": [blocks_, threads_], "lds_bytes_per_block": lds_,
                    "index_build_s": round(t_index, 2)},
     }
 
-    headline = args.rule == "C:T" and args.gap == 0 and args.read_len == 100 and args.genome_scale == 1.0
+    headline = args.config == "2" and not adhoc and args.read_len == 100 and args.genome_scale == 1.0 and args.genome == "uniform"
     kernel_name = "align_kernel<%d,%s,%s>" % (4 if read_len <= 128 else 8 if read_len <= 256 else 16, "true" if params.c.new_rule else "false",
                                               "true" if args.gap > 0 else "false")
     # ---- cpu_baseline + parity on a bounded sample (rank 0, N=1 only) + roofline ------------------
@@ -417,7 +434,7 @@ def main():
     out["roofline"] = roof
     if rank == 0 and world == 1 and cpu is not None and args.ref_sample > 0:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-        ref_cpu = time_reference(flags, args.rule, args.gap, read_len, args.ref_sample, threads, dev)
+        ref_cpu = time_reference(args.rule, args.gap, p_extra, read_kw, read_len, args.ref_sample if args.gap == 0 else args.ref_sample // 4, threads, dev)
         if ref_cpu is not None:  # the reference itself is the baseline; the port on the exact workload stays next to it
             out["config"]["cpu_port"] = cpu
             cpu = ref_cpu

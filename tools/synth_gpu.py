@@ -36,7 +36,54 @@ class Genome:
     pass
 
 
-def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=40000, repeat_len=300, repeat_div=0.12):
+# A repeat landscape shaped like the human genome's (shares of hg38 from RepeatMasker-style summaries, rounded): interspersed families as
+# (name, consensus length, share of the genome, divergence range of a copy from the consensus, copy length classes [(fraction of copies,
+# fraction of the consensus kept -- the 3' end, as truncated L1 copies keep it)]), plus tandem satellites.  About 45 % of the genome.
+REALISTIC_FAMILIES = [
+    ("Alu", 300, 0.105, (0.05, 0.18), [(1.0, 1.0)]),
+    ("L1", 6000, 0.17, (0.03, 0.25), [(0.55, 0.08), (0.25, 0.15), (0.12, 0.3), (0.06, 0.6), (0.02, 1.0)]),
+    ("MIR", 260, 0.03, (0.2, 0.32), [(1.0, 0.7)]),
+    ("L2", 3300, 0.035, (0.2, 0.32), [(0.7, 0.1), (0.3, 0.25)]),
+    ("LTR", 1000, 0.085, (0.08, 0.25), [(0.6, 0.5), (0.4, 1.0)]),
+    ("DNA", 800, 0.03, (0.15, 0.3), [(0.7, 0.3), (0.3, 0.8)]),
+]
+REALISTIC_SATELLITE = (171, 0.03, 0.02, 200_000)  # monomer length, share of the genome, divergence between monomers, array length
+
+
+def _plant_realistic(ids, L, scale_share, g, rng, device, consensus):
+    """Overwrites stretches of one contig (ids, uint8 base ids) with diverged copies of the families' consensus sequences."""
+    for (name, clen, share, (d_lo, d_hi), classes), cons in zip(REALISTIC_FAMILIES, consensus):
+        for frac, keep in classes:
+            ln = max(32, int(clen * keep))
+            n = int(L * share * scale_share * frac / ln)
+            if n <= 0 or L <= 2 * ln:
+                continue
+            starts = torch.from_numpy(rng.integers(0, L - ln, size=n)).to(device)
+            unit = cons[clen - ln:].repeat(n)  # the 3' part of the consensus
+            div = d_lo + (d_hi - d_lo) * torch.rand(n, generator=g, device=device)
+            mut = torch.rand(n * ln, generator=g, device=device) < div.repeat_interleave(ln)
+            unit = torch.where(mut, torch.randint(0, 4, unit.shape, generator=g, device=device, dtype=torch.uint8), unit)
+            rc = torch.rand(n, generator=g, device=device) < 0.5  # either orientation
+            unit = unit.view(n, ln)
+            unit = torch.where(rc[:, None], (3 - unit).flip(1), unit).reshape(-1)
+            idx = (starts[:, None] + torch.arange(ln, device=device)[None, :]).reshape(-1)
+            ids[idx] = unit
+            del starts, unit, mut, idx
+    mono, share, sdiv, alen = REALISTIC_SATELLITE
+    n_arr = max(1, int(L * share * scale_share / alen))
+    sat = consensus[-1]
+    for _ in range(n_arr):
+        if L <= 2 * alen:
+            break
+        p = int(rng.integers(0, L - alen))
+        arr = sat.repeat(alen // mono + 1)[:alen].clone()
+        mut = torch.rand(alen, generator=g, device=device) < sdiv
+        arr[mut] = torch.randint(0, 4, (int(mut.sum()),), generator=g, device=device, dtype=torch.uint8)
+        ids[p:p + alen] = arr
+
+
+def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=40000, repeat_len=300, repeat_div=0.12, realistic=False):
+    """realistic=True: instead of the single planted family, the repeat landscape of REALISTIC_FAMILIES (about 45 % of every contig)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     rng = np.random.default_rng(seed)
@@ -45,6 +92,10 @@ def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=4
     al_t = torch.tensor(al, dtype=torch.uint8, device=device)
     rv_t = torch.tensor(rv, dtype=torch.uint8, device=device)
     family = torch.randint(0, 4, (repeat_len,), generator=g, device=device, dtype=torch.uint8)
+    consensus = None
+    if realistic:
+        consensus = [torch.randint(0, 4, (f[1],), generator=g, device=device, dtype=torch.uint8) for f in REALISTIC_FAMILIES]
+        consensus.append(torch.randint(0, 4, (REALISTIC_SATELLITE[0],), generator=g, device=device, dtype=torch.uint8))
     G = Genome()
     G.names, G.sizes, G.ids, G.nmask_runs = NAMES[:n_contigs], sizes, [], []
     fw_words, rc_words, blocks = [], [], []
@@ -53,8 +104,10 @@ def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=4
     per_contig_rep = max(1, int(repeat_copies * scale) // n_contigs)
     for ci, L in enumerate(sizes):
         ids = torch.randint(0, 4, (L,), generator=g, device=device, dtype=torch.uint8)
+        if realistic:
+            _plant_realistic(ids, L, 1.0, g, rng, device, consensus)
         # planted repeat family, diverged copies
-        if per_contig_rep and L > 4 * repeat_len:
+        elif per_contig_rep and L > 4 * repeat_len:
             starts = torch.from_numpy(rng.integers(0, L - repeat_len, size=per_contig_rep)).to(device)
             idx = (starts[:, None] + torch.arange(repeat_len, device=device)[None, :]).reshape(-1)
             unit = family.repeat(per_contig_rep)
@@ -110,10 +163,17 @@ def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=4
     return G
 
 
-def make_reads(G, n, device, read_len=100, seed=2, p_conv=0.95, sub_rate=0.01, rev_frac=0.5, conv_from=1, conv_to=3):
-    """n reads as ASCII bytes (n*read_len uint8 tensor) plus the truth (contig, 0-based start, strand)."""
+def make_reads(G, n, device, read_len=100, seed=2, p_conv=0.95, sub_rate=0.01, rev_frac=0.5, conv_from=1, conv_to=3, indel_frac=0.0, indel_max=2,
+               del_base=None, del_frac=0.0, del_lo=20, del_hi=80):
+    """n reads as ASCII bytes (n*read_len uint8 tensor) plus the truth (contig, 0-based start, strand).
+    conv_to: one base id, or a list of ids (each converted base becomes one of them, uniformly: the multi-way rules).
+    indel_frac: share of reads with one insertion or deletion of 1..indel_max bases.
+    del_base / del_frac: share of reads with ONE base of that kind deleted between read positions del_lo and del_hi (config 5, BID-seq)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    out_len = read_len
+    pad = indel_max + 1 if (indel_frac > 0 or del_frac > 0) else 0
+    read_len = out_len + pad  # sample a longer window, cut the read out of it below
     # sample (contig, start) uniformly over non-N stretches long enough for a read
     segs = []
     for ci, runs in enumerate(G.nmask_runs):
@@ -137,8 +197,42 @@ def make_reads(G, n, device, read_len=100, seed=2, p_conv=0.95, sub_rate=0.01, r
         out[m] = G.ids[ci][(start[m][:, None] + ar[None, :])]
     rev = torch.rand(n, generator=g, device=device) < rev_frac
     out = torch.where(rev[:, None], (3 - out).flip(1), out)
+    if pad:  # one gap per chosen read, in read orientation: deletion = skip k window bases, insertion = k random bases
+        L = out_len
+        col = torch.arange(L, device=device)[None, :]
+        k = torch.zeros(n, dtype=torch.int64, device=device)
+        pos = torch.zeros(n, dtype=torch.int64, device=device)
+        ins = torch.zeros(n, dtype=torch.bool, device=device)
+        if indel_frac > 0:
+            has = torch.rand(n, generator=g, device=device) < indel_frac
+            kk = 1 + (torch.rand(n, generator=g, device=device) * indel_max).long().clamp(max=indel_max - 1)
+            k = torch.where(has, kk, k)
+            pos = torch.where(has, 10 + (torch.rand(n, generator=g, device=device) * (L - 20)).long(), pos)
+            ins = has & (torch.rand(n, generator=g, device=device) < 0.5)
+        if del_frac > 0:
+            want = torch.rand(n, generator=g, device=device) < del_frac
+            p0 = del_lo + (torch.rand(n, generator=g, device=device) * (del_hi - del_lo)).long()
+            cand = (out[:, :L] == del_base) & (col >= p0[:, None]) & (col < del_hi)  # the first such base at or behind p0
+            first = torch.where(cand.any(dim=1), cand.float().argmax(dim=1), torch.full_like(p0, -1))
+            ok = want & (first >= 0)
+            k = torch.where(ok, torch.ones_like(k), k)
+            pos = torch.where(ok, first, pos)
+            ins = ins & ~ok
+        dele = (k > 0) & ~ins
+        idx = col + torch.where(dele[:, None] & (col >= pos[:, None]), k[:, None], torch.zeros_like(col))
+        idx = idx - torch.where(ins[:, None] & (col >= (pos + k)[:, None]), k[:, None], torch.zeros_like(col))
+        cut = torch.gather(out, 1, idx.clamp(0, read_len - 1))
+        in_ins = ins[:, None] & (col >= pos[:, None]) & (col < (pos + k)[:, None])
+        cut = torch.where(in_ins, torch.randint(0, 4, cut.shape, generator=g, device=device, dtype=torch.uint8), cut)
+        out = cut
+        read_len = out_len
+    tos = list(conv_to) if isinstance(conv_to, (list, tuple)) else [conv_to]
     conv = (out == conv_from) & (torch.rand(out.shape, generator=g, device=device) < p_conv)
-    out = torch.where(conv, torch.full_like(out, conv_to), out)
+    if len(tos) == 1:
+        out = torch.where(conv, torch.full_like(out, tos[0]), out)
+    else:
+        pick_to = torch.tensor(tos, dtype=torch.uint8, device=device)[torch.randint(0, len(tos), out.shape, generator=g, device=device)]
+        out = torch.where(conv, pick_to, out)
     sub = torch.rand(out.shape, generator=g, device=device) < sub_rate
     out = torch.where(sub, (out + torch.randint(1, 4, out.shape, generator=g, device=device, dtype=torch.uint8)) % 4, out)
     ascii_t = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
