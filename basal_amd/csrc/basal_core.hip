@@ -1354,11 +1354,13 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     // kernel ran at exactly that ceiling, independent of occupancy, before reads were taken in chunks).
     // Every wave leaves this loop: the queue head only grows, and the iteration bound is a watchdog
     // against an internal error (a wave cannot legitimately take more than n reads).
-    const bool listed = COLD(order) != nullptr;
-    uint32_t n_items = cx.n;
-    if (COLD(n_ptr)) { n_items = *COLDP(const uint32_t, n_ptr); n_items = n_items < cx.n ? n_items : cx.n; }  // cx.n: the capacity of the list
-    if (n_items == 0) return;  // (a read-length class without reads: no queue traffic)
+    // (the pipeline's extras -- a list of read numbers, its length in device memory -- are re-read from the kernel arguments where they
+    // are used, once per chunk of reads: held in registers across the work loop they cost the standard launch spills)
+#define LISTED (COLD(order) != nullptr)
+    if (COLD(n_ptr) && *COLDP(const uint32_t, n_ptr) == 0) return;  // (a read-length class without reads: no queue traffic)
     for (uint32_t iter = 0;; iter++) {
+        uint32_t n_items = cx.n;
+        if (COLD(n_ptr)) { n_items = *COLDP(const uint32_t, n_ptr); n_items = n_items < cx.n ? n_items : cx.n; }  // cx.n: the capacity of the list
         // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
         if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(ballot(1)), 0, iter); break; }
         uint32_t base = 0;
@@ -1372,7 +1374,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         // is being aligned, so a read starts on data that is already in registers (2 memory round trips per chunk
         // instead of 2 per read).
         if ((uint32_t)lane < end - base) {
-            const uint32_t rn = listed ? COLDP(const uint32_t, order)[base + lane] : base + (uint32_t)lane;
+            const uint32_t rn = LISTED ? COLDP(const uint32_t, order)[base + lane] : base + (uint32_t)lane;
             L.rno[lane] = rn;
             L.desc[lane] = cx.reads[rn];
         }
@@ -1383,7 +1385,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         load_bases<NWT>(cx, nrd, base, npc, lane, npre);
         PH(PH_CHUNK);
         for (uint32_t w = base; w < end; w++) {
-            const uint32_t r = listed ? rfl(L.rno[w - base]) : w;  // the read's number in the batch
+            const uint32_t r = LISTED ? rfl(L.rno[w - base]) : w;  // the read's number in the batch
             if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x30000u | (uint32_t)__popcll(ballot(1)), 0, r); break; }
             const basal_read rd = nrd;
             const int pc = npc;
@@ -1419,7 +1421,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         wave_sync();
         static_assert(WORK_CHUNK * sizeof(basal_result) == 64 * sizeof(uint32_t), "one dword per lane");
         if ((uint32_t)lane < (end - base) * (uint32_t)(sizeof(basal_result) / 4)) {
-            if (!listed) ((uint32_t *)(COLDP(basal_result, results) + base))[lane] = ((const uint32_t *)L.res)[lane];
+            if (!LISTED) ((uint32_t *)(COLDP(basal_result, results) + base))[lane] = ((const uint32_t *)L.res)[lane];
             else ((uint32_t *)(COLDP(basal_result, results) + L.rno[lane >> 3]))[lane & 7] = ((const uint32_t *)L.res)[lane];  // still one store instruction per chunk
         }
     }
