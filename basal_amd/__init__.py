@@ -8,5 +8,5 @@ from .core import (  # noqa: F401
     BasalError, Core, Params, Reference, lib, lib_path, build,
     basal_hit, basal_read, basal_result, basal_params, basal_stale, basal_mate, READ_ALLMODES,
     STREAM_NONE, STREAM_BEST, STREAM_ALL, STALE_NONE, STALE_CARRY,
-    Pipe, basal_rawread, basal_pipe_opts, basal_batch_stats, PIPE_OUT_SAM, PIPE_OUT_RESULTS, FMT_FASTQ, FMT_FASTA, RAWREAD_DTYPE,
+    Multi, shard_range, Pipe, basal_rawread, basal_pipe_opts, basal_batch_stats, PIPE_OUT_SAM, PIPE_OUT_RESULTS, FMT_FASTQ, FMT_FASTA, RAWREAD_DTYPE,
 )

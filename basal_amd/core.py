@@ -124,6 +124,13 @@ SYMBOLS = [
     ("basal_pipe_cancel", _i, [_vp]),
     ("basal_pipe_stop", _i, [_vp]),
     ("basal_pipe_rewind", _i, [_vp]),
+    ("basal_shard_range", None, [_u64, _u32, _u32, _P(_u64), _P(_u64)]),
+    ("basal_multi_create", _i, [_P(basal_params), _P(_i), _i, _P(_vp)]),
+    ("basal_multi_destroy", None, [_vp]),
+    ("basal_multi_ndev", _i, [_vp]),
+    ("basal_multi_core", _vp, [_vp, _i]),
+    ("basal_multi_upload", _i, [_vp, _vp, _i, _P(_u32)]),
+    ("basal_multi_align_batch", _i, [_vp, _vp, _u64, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _P(_u64), _vp]),
     ("basal_pipe_set_read_range", _i, [_vp, _u32, _u32]),
     ("basal_host_params_defaults", None, [_P(basal_params)]),
     ("basal_host_params_set_seed_size", _i, [_P(basal_params), _i]),
@@ -439,3 +446,50 @@ class Pipe:
 
     def set_read_range(self, next_index, read_end=0xFFFFFFFF):
         _check(lib().basal_pipe_set_read_range(self.h, next_index, read_end), "pipe_set_read_range")
+
+
+class Multi:
+    """basal_multi_t: one core per listed GPU, reads sharded by read number, records gathered with RCCL."""
+
+    def __init__(self, params, devices):
+        self.params = params
+        self.h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().basal_multi_create(C.byref(params.c), arr, len(devices), C.byref(self.h)), "multi_create")
+
+    def close(self):
+        if self.h:
+            lib().basal_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, ref, build_on_gpu=False):
+        mk = C.c_uint32()
+        _check(lib().basal_multi_upload(self.h, ref.h, int(build_on_gpu), C.byref(mk)), "multi_upload")
+        return mk.value
+
+    def align_batch(self, bases, reads, stream_mode=STREAM_NONE, stream_cap=0, carry=None, stales=None):
+        n = len(reads)
+        res = np.zeros(n, RESULT_DTYPE)
+        stream = np.zeros(max(stream_cap, 1), HIT_DTYPE)
+        used = C.c_uint64()
+        cy = np.zeros((2, 2), np.uint8) if carry is None else np.array(carry, np.uint8).reshape(2, 2).copy()
+        bases = np.ascontiguousarray(bases, np.uint8)
+        reads = np.ascontiguousarray(reads)
+        stales = np.zeros(0, STALE_DTYPE) if stales is None else np.ascontiguousarray(stales)
+        rc = lib().basal_multi_align_batch(self.h, bases.ctypes.data, len(bases), reads.ctypes.data, n, stales.ctypes.data if len(stales) else None, len(stales),
+                                           stream_mode, res.ctypes.data, stream.ctypes.data if stream_mode else None, stream_cap, C.byref(used), cy.ctypes.data)
+        _check(rc, "multi_align_batch")
+        return res, stream[: used.value], cy
+
+
+def shard_range(n, rank, world):
+    """basal_shard_range (the native sharding rule; no GPU needed)."""
+    b, e = C.c_uint64(), C.c_uint64()
+    lib().basal_shard_range(n, rank, world, C.byref(b), C.byref(e))
+    return b.value, e.value

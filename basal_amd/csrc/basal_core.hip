@@ -1691,6 +1691,12 @@ int basal_launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, 
     static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
     return launch_align(c, d_bases, nbases_dev, d_reads, n, d_stales, nstale, max_len, stream_mode, d_results, d_stream, stream_cap, d_stream_used, zero_carry, s, ex);
 }
+int basal_launch_align_carry(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
+                             uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2],
+                             hipStream_t s, const basal_align_extra *ex) {
+    static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
+    return launch_align(c, d_bases, nbases_dev, d_reads, n, d_stales, nstale, max_len, stream_mode, d_results, d_stream, stream_cap, d_stream_used, carry ? carry : zero_carry, s, ex);
+}
 int basal_ensure_launch_geometry(basal_core *c) { return ensure_launch_geometry(c); }
 int basal_report_guard(const unsigned int *guard) { return report_guard(guard); }
 

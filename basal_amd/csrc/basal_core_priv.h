@@ -52,6 +52,9 @@ struct basal_align_extra {
 int basal_launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
                        uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, hipStream_t s,
                        const basal_align_extra *ex);
+int basal_launch_align_carry(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
+                             uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2],
+                             hipStream_t s, const basal_align_extra *ex);
 int basal_ensure_launch_geometry(basal_core *c);  // sizes c->grid (largest grid any instantiation uses) and the core's own scratch
 int basal_report_guard(const unsigned int *guard);  // BASAL_OK, or BASAL_EDEVICE + message if the kernel's bounds ledger is not clean
 

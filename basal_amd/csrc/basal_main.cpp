@@ -294,6 +294,7 @@ struct Cli {
     basal_params P;
     std::string qa, qb, ref_file, out_file, rule, cmdline;
     int threads = 1, verbose = 1, device = 0, sam_header = 1;
+    std::vector<int> devices;  // -G 0,1,...: the GPUs the reads of every batch are sharded over
     uint32_t read_start = 1, read_end = ~0u;
     size_t batch = 0;
     bool cpu_index = false;
@@ -626,8 +627,104 @@ void run_se(Cli &cli, basal_pipe_t *pipe, const SePlan &plan, Output &out, SeSta
     if (!reader_err.empty()) die(reader_err);
 }
 
+// one batch through one GPU (basal_core_align_batch) or sharded over several (basal_multi_align_batch: RCCL gather of the records)
+struct Aligner {
+    basal_core_t *core = nullptr;
+    basal_multi_t *multi = nullptr;
+    int run(const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, const basal_stale *stales, uint32_t nstale, int mode, basal_result *res,
+            basal_hit *stream, uint64_t cap, uint64_t *used, uint8_t carry[2][2]) {
+        return multi ? basal_multi_align_batch(multi, bases, nbases, reads, n, stales, nstale, mode, res, stream, cap, used, carry)
+                     : basal_core_align_batch(core, bases, nbases, reads, n, stales, nstale, mode, res, stream, cap, used, carry);
+    }
+};
+
+// =========================================================================== single-end with host-side QC and SAM text (several GPUs)
+// The reads of every batch are sharded over the GPUs by read number; FilterReads and s_OutHit run here on `-p` host threads
+// (basal_host_filter_read / basal_host_format_se), the way round 1's command line did on one GPU.
+void run_se_host(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, SeStats &st) {
+    const basal_params &P = cli.P;
+    const int threads = cli.threads;
+    const size_t batch = cli.batch ? cli.batch : (1u << 20);
+    Reader ra;
+    if (!ra.open(cli.qa.c_str())) die("failed to open read file (check -a option): " + cli.qa);
+    skip_reads(ra, P, cli.read_start, 0);
+    std::vector<Rec> recs;
+    std::vector<uint8_t> bases;
+    std::vector<basal_read> descs;
+    std::vector<basal_result> results;
+    std::vector<basal_hit> stream;
+    std::vector<basal_stale> stales;
+    basal_stale_tracker_t *tracker = basal_host_stale_new(&P);
+    uint8_t carry[2][2] = {{0, 0}, {0, 0}};
+    const int smode = P.report_repeat_hits == 2 ? BASAL_STREAM_BEST : BASAL_STREAM_NONE;
+    while (load_batch(ra, P, cli.read_end, batch, 0, recs, (size_t)3500 << 20)) {
+        const size_t n = recs.size();
+        parallel_for(n, threads, [&](size_t b, size_t e, int) {
+            for (size_t i = b; i < e; i++) recs[i].qc_failed = basal_host_filter_read(&P, recs[i].seq.data(), recs[i].qual.data(), &recs[i].max_snp);
+        });
+        descs.assign(n, basal_read{});
+        bases.clear();
+        stales.clear();
+        basal_host_stale_begin_batch(tracker);
+        for (size_t i = 0; i < n; i++) {
+            basal_read &d = descs[i];
+            d.index = recs[i].index;
+            d.readset = 0;
+            d.stale_idx = BASAL_STALE_NONE;
+            if (recs[i].qc_failed) { d.len = 0; continue; }
+            uint32_t len = (uint32_t)strlen(recs[i].seq.data());
+            d.len = (uint16_t)len;
+            d.max_snp = (uint8_t)recs[i].max_snp;
+            d.seq_off = (uint32_t)bases.size();
+            bases.insert(bases.end(), recs[i].seq.begin(), recs[i].seq.begin() + len);
+            basal_stale se;
+            if (basal_host_stale_visit(tracker, recs[i].seq.data(), len, 0, 0, (uint32_t)i, &se)) {
+                d.stale_idx = (uint32_t)stales.size();
+                stales.push_back(se);
+            }
+        }
+        results.assign(n, basal_result{});
+        uint64_t cap = smode ? (uint64_t)n * 4 + 1024 : 0, used = 0;
+        for (;;) {
+            stream.resize(cap ? cap : 1);
+            uint8_t cy[2][2];
+            memcpy(cy, carry, 4);
+            int rc = al.run(bases.data(), bases.size(), descs.data(), (uint32_t)n, stales.data(), (uint32_t)stales.size(), smode, results.data(), stream.data(), cap, &used, cy);
+            if (rc == BASAL_EOVERFLOW) { cap = used + 1024; continue; }
+            if (rc) die(std::string("align_batch: ") + basal_last_error());
+            memcpy(carry, cy, 4);
+            break;
+        }
+        std::vector<std::string> chunks((size_t)std::max(threads, 1));
+        std::vector<uint64_t> cnt((size_t)std::max(threads, 1) * 3, 0);
+        parallel_for(n, threads, [&](size_t b, size_t e, int tid) {
+            std::string &o = chunks[(size_t)tid];
+            std::vector<char> line(1 << 16);
+            for (size_t i = b; i < e; i++) {
+                const Rec &rc_ = recs[i];
+                const basal_result &rs = results[i];
+                size_t need = 4096 + rc_.name.size() + 2 * rc_.seq.size() + (size_t)(rs.stream_n + 1) * (1024 + 2 * rc_.seq.size());
+                if (line.size() < need) line.resize(need);
+                int64_t w = basal_host_format_se(&P, R, rc_.name.c_str(), rc_.seq.data(), rc_.qual.data(), 0, rc_.qc_failed, &rs, stream.data(), line.data(), line.size());
+                if (w < 0) die(std::string("format: ") + basal_last_error());
+                o.append(line.data(), (size_t)w);
+                if (!rc_.qc_failed && rs.best_level != 0xFF) {
+                    uint32_t sum = (uint32_t)rs.n_hit + rs.n_chit;
+                    if (sum == 1) { cnt[3 * tid]++; cnt[3 * tid + 1]++; }
+                    else { cnt[3 * tid + 2]++; if (P.report_repeat_hits) cnt[3 * tid]++; }
+                }
+            }
+        });
+        for (auto &c : chunks) out.write(c.data(), c.size());
+        for (size_t t = 0; t < chunks.size(); t++) { st.n_aligned += cnt[3 * t]; st.n_unique += cnt[3 * t + 1]; st.n_multiple += cnt[3 * t + 2]; }
+        st.n_reads += n;
+    }
+    basal_host_stale_free(tracker);
+    ra.close();
+}
+
 // =========================================================================== paired-end: GPU alignment, host pairing
-void run_pe(Cli &cli, basal_core_t *core, basal_ref_t *R, Output &out, uint32_t pst[9], uint64_t &n_pairs, double &t_gpu) {
+void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9], uint64_t &n_pairs, double &t_gpu) {
     basal_params &P = cli.P;
     const int threads = cli.threads;
     const size_t batch = cli.batch ? cli.batch : (1u << 20);
@@ -693,8 +790,8 @@ void run_pe(Cli &cli, basal_core_t *core, basal_ref_t *R, Output &out, uint32_t 
             stream.resize(cap);
             uint8_t cy[2][2];
             memcpy(cy, carry, 4);
-            int rc = basal_core_align_batch(core, bases.data(), bases.size(), descs.data(), (uint32_t)(2 * np), stales.data(), (uint32_t)stales.size(),
-                                            BASAL_STREAM_ALL, results.data(), stream.data(), cap, &used, cy);
+            int rc = al.run(bases.data(), bases.size(), descs.data(), (uint32_t)(2 * np), stales.data(), (uint32_t)stales.size(), BASAL_STREAM_ALL, results.data(),
+                            stream.data(), cap, &used, cy);
             if (rc == BASAL_EOVERFLOW) { cap = used + 4096; continue; }
             if (rc) die(std::string("align_batch: ") + basal_last_error());
             memcpy(carry, cy, 4);
@@ -779,7 +876,13 @@ int main(int argc, char **argv) {
             case 'S': P.randseed = (uint32_t)atoi(v); break;
             case '3': die("-3 (3-nucleotide mode) is not supported by the MI355X build");
             case 'D': die("-D (RRBS digestion sites) is not supported by the MI355X build");
-            case 'G': cli.device = atoi(v); break;  // extension: HIP device ordinal
+            case 'G': {  // extension: HIP device ordinal, or a list 0,1,2,... to shard every batch's reads over several GPUs
+                cli.devices.clear();
+                for (const char *q = v; *q;) { cli.devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+                if (cli.devices.empty()) die("-G needs a device ordinal or a comma-separated list of them");
+                cli.device = cli.devices[0];
+                break;
+            }
             case 'Z': cli.batch = (size_t)atol(v); break;  // extension: reads per GPU batch
             case 'h': die("see the BASAL 1.8.1 usage text; this build accepts the same options");
             default: die(std::string("unknown option: ") + a, i);
@@ -792,14 +895,20 @@ int main(int argc, char **argv) {
 
     double t0 = now();
     basal_core_t *core = nullptr;
-    if (basal_core_create(&P, cli.device, &core)) die(std::string("cannot create the GPU core: ") + basal_last_error());
+    basal_multi_t *multi = nullptr;
+    if (cli.devices.empty()) cli.devices.push_back(cli.device);
+    const bool several = cli.devices.size() > 1 || getenv("BASAL_FORCE_MULTI") != nullptr;  // (the variable: the sharded path on a one-GPU box, for tests)
+    if (several) {
+        if (basal_multi_create(&P, cli.devices.data(), (int)cli.devices.size(), &multi)) die(std::string("cannot set up the GPUs: ") + basal_last_error());
+        core = basal_multi_core(multi, 0);
+    } else if (basal_core_create(&P, cli.device, &core)) die(std::string("cannot create the GPU core: ") + basal_last_error());
     // single-end: the pipeline's buffers are page-locked by a helper thread while the reference is read and staged
     SePlan plan;
     basal_pipe_t *pipe = nullptr;
     std::thread pipe_thread;
     std::string pipe_err;
     double t_pipe = 0;
-    if (!P.pairend) {
+    if (!P.pairend && !several) {
         plan = plan_se(cli);
         pipe_thread = std::thread([&] {
             const double a0 = now();
@@ -812,10 +921,9 @@ int main(int argc, char **argv) {
     if (basal_host_ref_load(&P, cli.ref_file.c_str(), &R)) die(basal_last_error());
     double t1 = now();
     uint32_t mk = 0;
-    if (cli.cpu_index) {
-        if (basal_host_ref_build_index(R, &P, cli.threads)) die(basal_last_error());
-        if (basal_host_ref_upload(R, core, 0, &mk)) die(basal_last_error());
-    } else if (basal_host_ref_upload(R, core, 1, &mk)) die(basal_last_error());
+    if (cli.cpu_index && basal_host_ref_build_index(R, &P, cli.threads)) die(basal_last_error());
+    if (several) { if (basal_multi_upload(multi, R, cli.cpu_index ? 0 : 1, &mk)) die(basal_last_error()); }
+    else if (basal_host_ref_upload(R, core, cli.cpu_index ? 0 : 1, &mk)) die(basal_last_error());
     {
         const uint32_t nc = basal_host_ref_ncontig(R);
         std::vector<const char *> names(nc);
@@ -857,7 +965,8 @@ int main(int argc, char **argv) {
         uint32_t pst[9] = {0};
         uint64_t n_pairs = 0;
         double t_gpu = 0;
-        run_pe(cli, core, R, out, pst, n_pairs, t_gpu);
+        Aligner al{several ? nullptr : core, multi};
+        run_pe(cli, al, R, out, pst, n_pairs, t_gpu);
         out.close();
         if (cli.verbose >= 1) {
             fprintf(stderr, "[BASAL-MI355X] total read pairs: %llu \ttotal time:  %.2f secs (GPU batches %.3f s)\n", (unsigned long long)n_pairs, now() - t0, t_gpu);
@@ -867,11 +976,16 @@ int main(int argc, char **argv) {
     } else {
         SeStats st;
         double t_wait = 0;
-        pipe_thread.join();
-        if (!pipe) die("cannot create the pipeline: " + pipe_err);
-        st.t_create = t_pipe;
-        t3 = now();
-        run_se(cli, pipe, plan, out, st, t_wait);
+        if (several) {
+            Aligner al{nullptr, multi};
+            run_se_host(cli, al, R, out, st);
+        } else {
+            pipe_thread.join();
+            if (!pipe) die("cannot create the pipeline: " + pipe_err);
+            st.t_create = t_pipe;
+            t3 = now();
+            run_se(cli, pipe, plan, out, st, t_wait);
+        }
         out.close();
         double t4 = now();
         if (cli.verbose >= 1) {
@@ -889,7 +1003,8 @@ int main(int argc, char **argv) {
     fflush(stderr);
     if (!getenv("BASAL_CLEAN_EXIT")) _exit(0);  // everything is written: leave the gigabytes of page-locked and device memory to the OS
     if (pipe) basal_pipe_destroy(pipe);
-    basal_core_destroy(core);
+    if (multi) basal_multi_destroy(multi);
+    else basal_core_destroy(core);
     basal_host_ref_free(R);
     return 0;
 }

@@ -9,10 +9,10 @@ import numpy as np
 
 
 def shard_range(n, rank, world):
-    """Contiguous slice [begin, end) of n reads for this rank; slices differ by at most one read."""
-    base, extra = divmod(n, world)
-    begin = rank * base + min(rank, extra)
-    return begin, begin + base + (1 if rank < extra else 0)
+    """Contiguous slice [begin, end) of n reads for this rank; slices differ by at most one read. This IS the native rule: the C
+    function basal_shard_range of libbasal_amd.so, the one basal_multi_align_batch (the `basal -G 0,1,...` path) shards with."""
+    from .core import shard_range as native
+    return native(n, rank, world)
 
 
 def gather_results(local, n_total, rank, world, dist, device=None):

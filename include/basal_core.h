@@ -261,6 +261,23 @@ int basal_pipe_rewind(basal_pipe_t *p);
  * (text form: records from read_end on are ignored). Only with nothing in flight. */
 int basal_pipe_set_read_range(basal_pipe_t *p, uint32_t next_index, uint32_t read_end);
 
+/* ---- several GPUs of one node: reads sharded by read number, hit records gathered with RCCL ----
+ * The reference fans batches out to host threads (main.cpp:60-92); this fans the reads of a batch out to GPUs. Every GPU holds the whole
+ * reference + index, aligns a contiguous range of the batch's reads, and ONE ncclGather per batch moves the 32-byte records to GPU 0. */
+/* [begin, end) of the reads rank `rank` of `world` takes of a batch of n (contiguous, sizes differ by at most one). No GPU needed. */
+void basal_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *begin, uint64_t *end);
+typedef struct basal_multi basal_multi_t;
+typedef struct basal_ref basal_ref_t; /* (host-side reference object, see basal_host_ref_* below) */
+int basal_multi_create(const basal_params *p, const int *devices, int ndev, basal_multi_t **out); /* one basal_core_t per device + the RCCL communicators */
+void basal_multi_destroy(basal_multi_t *m);
+int basal_multi_ndev(const basal_multi_t *m);
+basal_core_t *basal_multi_core(basal_multi_t *m, int rank);
+int basal_multi_upload(basal_multi_t *m, const basal_ref_t *r, int build_index_on_gpu, uint32_t *max_kmer_num); /* basal_host_ref_upload on every GPU */
+/* basal_core_align_batch over all GPUs: same arguments, same results. */
+int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, const basal_stale *stales,
+                            uint32_t nstale, int stream_mode, basal_result *results, basal_hit *stream, uint64_t stream_cap, uint64_t *stream_used,
+                            uint8_t carry[2][2]);
+
 /* ---- host helpers ---- */
 void basal_host_params_defaults(basal_params *p);                    /* Param::Param, param.cpp:7-68 */
 int basal_host_params_set_seed_size(basal_params *p, int n);         /* Param::SetSeedSize, param.cpp:108-115 */

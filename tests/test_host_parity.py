@@ -119,7 +119,7 @@ def test_filter_reads_matches_oracle(name, extra):
 def test_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(H.ROOT, "include", "basal_core.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(basal_(?:core|host|last|pipe)_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(basal_(?:core|host|last|pipe|multi|shard)_[a-z_0-9]+)\s*\(", hdr))
     assert len(declared) >= 35
     L = C.CDLL(B.lib_path())
     for s in sorted(declared):

@@ -5,7 +5,8 @@
 # The summary (tools/pmc_summary.py) is what gets copied to profiles/.
 set -e
 TAG=${1:-run}
-ARGS=${2:---cpu-sample 0 --steps 4}
+ARGS=${2:---cpu-sample 0 --ref-sample 0 --steps 4}
+export BASAL_BENCH_NO_H2H=1
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"

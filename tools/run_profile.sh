@@ -16,3 +16,12 @@ echo "[profile] kernel-trace bench done: $(cut -c80-140 gpurun_out/${TAG}_bench.
 grep -h "align_kernel\|fill_flanks\|emit_pairs\|split_counts" gpurun_out/prof_$TAG/*/*kernel_stats.csv | cut -c1-60,150-400 || true
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete
 bash tools/run_pmc.sh $TAG 2>&1 | grep -v "^    @"
+# the other configs: bench line (with its roofline and cpu_baseline objects) + counter passes
+for C in 4 5p; do
+  python3 bench.py --config $C --steps 5 > gpurun_out/${TAG}_c${C}_bench.json 2> gpurun_out/${TAG}_c${C}_bench.err || true
+  echo "[profile] config $C: $(cut -c80-150 gpurun_out/${TAG}_c${C}_bench.json)"
+  bash tools/run_pmc.sh ${TAG}_c${C} "--config $C --cpu-sample 0 --ref-sample 0 --steps 3" 2>&1 | grep -v "^    @" | tail -30
+done
+python3 bench.py --genome realistic --steps 3 > gpurun_out/${TAG}_realistic_bench.json 2> gpurun_out/${TAG}_realistic_bench.err || true
+echo "[profile] realistic genome: $(cut -c80-150 gpurun_out/${TAG}_realistic_bench.json)"
+bash tools/run_pmc.sh ${TAG}_realistic "--genome realistic --cpu-sample 0 --ref-sample 0 --steps 2" 2>&1 | grep -v "^    @" | tail -30
