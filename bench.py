@@ -63,7 +63,7 @@ def spawn_ranks(n):
     return subprocess.run(cmd).returncode
 
 
-def time_reference(rule, gap, extra_flags, read_kw, read_len, n_reads, cores, dev):
+def time_reference(rule, gap, extra_flags, read_kw, read_len, n_reads, cores, dev, realistic=False):
     """The TRUE reference binary (oracle/_ref/basal, built from /root/reference by oracle/Makefile.ref and shipped with the snapshot)
     timed on this box's host cores.  It only reads files and rebuilds its index on every run, and an hg38-sized FASTA would take it
     many minutes, so it runs on a density-equivalent down-scaled genome: 50 Mbp with -s 12 gives the 3-letter seeds the ~40 index
@@ -82,7 +82,7 @@ def time_reference(rule, gap, extra_flags, read_kw, read_len, n_reads, cores, de
     d = tempfile.mkdtemp(prefix="basal_ref_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         p = B.Params(rule, ["-M", rule])
-        G = synth_gpu.make_genome(p, dev, scale=50e6 / 3.088e9, seed=7, repeat_copies=650)
+        G = synth_gpu.make_genome(p, dev, scale=50e6 / 3.088e9, seed=7, repeat_copies=650, realistic=realistic)
         fa, fq = os.path.join(d, "g.fa"), os.path.join(d, "r.fq")
         synth_files.write_fasta(fa, G)
         with open(fq, "wb") as f:
@@ -105,7 +105,7 @@ def time_reference(rule, gap, extra_flags, read_kw, read_len, n_reads, cores, de
         secs = max(t_full - t_idle, 1e-3)
         return {"value": n_reads / secs / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
                 "sample": "the unmodified reference binary (oracle/_ref/basal -p %d) on %d reads of the same kind on a density-equivalent down-scaled genome "
-                          "(50 Mbp, -s 12: ~40 index entries per seed as on 3.09 Gbp at -s 16); align time = wall %.2f s minus %.2f s of the same command with -E 0 "
+                          "(50 Mbp" + (" with the same repeat landscape" if realistic else "") + ", -s 12: ~40 index entries per seed as on 3.09 Gbp at -s 16); align time = wall %.2f s minus %.2f s of the same command with -E 0 "
                           "(load + index build); %.0f CPU-seconds of alignment" % (cores, n_reads, t_full, t_idle, secs * cores)}
     except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
         log("reference timing failed: %r" % (e,))
@@ -434,7 +434,8 @@ def main():
     out["roofline"] = roof
     if rank == 0 and world == 1 and cpu is not None and args.ref_sample > 0:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-        ref_cpu = time_reference(args.rule, args.gap, p_extra, read_kw, read_len, args.ref_sample if args.gap == 0 else args.ref_sample // 4, threads, dev)
+        ref_cpu = time_reference(args.rule, args.gap, p_extra, read_kw, read_len, (args.ref_sample if args.gap == 0 else args.ref_sample // 4) // (8 if args.genome == "realistic" else 1),
+                                 threads, dev, realistic=args.genome == "realistic")
         if ref_cpu is not None:  # the reference itself is the baseline; the port on the exact workload stays next to it
             out["config"]["cpu_port"] = cpu
             cpu = ref_cpu
