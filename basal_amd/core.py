@@ -124,6 +124,8 @@ SYMBOLS = [
     ("basal_pipe_cancel", _i, [_vp]),
     ("basal_pipe_stop", _i, [_vp]),
     ("basal_pipe_rewind", _i, [_vp]),
+    ("basal_core_align_pairs_batch", _i, [_vp, _vp, _u64, _vp, _u32, _vp, _u32, _vp, _vp, _u64, _P(_u64), _vp, _vp]),
+    ("basal_host_format_pe_records", C.c_int64, [_P(basal_params), _vp, _P(basal_mate), _P(basal_mate), _vp, _u32, C.c_char_p, C.c_size_t]),
     ("basal_shard_range", None, [_u64, _u32, _u32, _P(_u64), _P(_u64)]),
     ("basal_multi_create", _i, [_P(basal_params), _P(_i), _i, _P(_vp)]),
     ("basal_multi_destroy", None, [_vp]),

@@ -1498,6 +1498,7 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_names); hipFree(c->d_name_off);
+    hipFree(c->d_pe_pairs); hipFree(c->d_pe_recs); hipFree(c->d_pe_work); hipFree(c->d_pe_misc);
     hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -1835,4 +1836,102 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
         }
     }
     return ret;
+}
+
+
+// basal_core_align_batch + the pairing kernel of basal_pe.hip, the hit streams never leaving the device
+extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t npairs, const basal_stale *stales,
+                                            uint32_t nstale, basal_pe_pair *pairs_out, basal_pe_rec *recs_out, uint64_t recs_cap, uint64_t *recs_used, uint32_t stats[9],
+                                            uint8_t carry[2][2]) {
+    const uint32_t n = 2 * npairs;
+    if (!c || (npairs && (!bases || !reads || !pairs_out || !recs_out || !recs_used))) { g_err = "align_pairs_batch: null argument"; return BASAL_EINVAL; }
+    if (npairs > 0x7FFFFFFFu / 2) { g_err = "align_pairs_batch: too many pairs in one batch"; return BASAL_EINVAL; }
+    if (nbases > 0xFFFFFFFFull) { g_err = "align_pairs_batch: more than 4 GiB of bases in one batch (basal_read.seq_off is 32-bit); split the batch"; return BASAL_EINVAL; }
+    *recs_used = 0;
+    if (n == 0) return BASAL_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t max_len = 0;
+    const uint32_t K = c->p.seed_size, I = c->p.index_interval;
+    for (uint32_t i = 0; i < n; i++) {
+        const basal_read &r = reads[i];
+        if (r.len == 0) continue;
+        if (r.len > BASAL_MAXREADLEN || (uint64_t)r.seq_off + r.len > nbases) { g_err = "align_pairs_batch: read descriptor out of range"; return BASAL_EINVAL; }
+        if (r.max_snp > BASAL_MAXSNPS) { g_err = "align_pairs_batch: max_snp > 15"; return BASAL_EINVAL; }
+        if (r.stale_idx != BASAL_STALE_NONE) {
+            if (!stales || r.stale_idx >= nstale) { g_err = "align_pairs_batch: stale_idx outside the stale table"; return BASAL_EINVAL; }
+            const uint32_t src = stales[r.stale_idx].src;
+            if (src != BASAL_STALE_CARRY && (src >= i || reads[src].len < K + I - 1)) { g_err = "align_pairs_batch: basal_stale.src must name an earlier aligned read"; return BASAL_EINVAL; }
+        }
+        if (r.len > max_len) max_len = r.len;
+    }
+    if (max_len == 0) max_len = 1;
+    int rc;
+    if ((rc = grow(c->d_bases, c->cap_bases, nbases + 64))) return rc;
+    if (n > c->cap_reads) { hipFree(c->d_results); c->d_results = nullptr; }
+    if ((rc = grow(c->d_reads, c->cap_reads, n))) return rc;
+    if (nstale && (rc = grow(c->d_stales, c->cap_stales, nstale))) return rc;
+    if (!c->d_results) HIP_TRY(hipMalloc(&c->d_results, c->cap_reads * sizeof(basal_result)));
+    if ((rc = grow(c->d_pe_pairs, c->cap_pe_pairs, npairs))) return rc;
+    if ((rc = grow(c->d_pe_recs, c->cap_pe_recs, recs_cap ? recs_cap : 1))) return rc;
+    if (!c->d_pe_misc) HIP_TRY(hipMalloc(&c->d_pe_misc, 16 * sizeof(unsigned long long)));
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_bases, bases, nbases, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
+    if (nstale) HIP_TRY(hipMemcpyAsync(c->d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
+    static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
+    // the hit streams stay on the device: a first guess of their size, doubled until every mate's log fits
+    uint64_t stream_cap = c->cap_stream > (uint64_t)n * 8 + 4096 ? c->cap_stream : (uint64_t)n * 8 + 4096;
+    unsigned long long used = 0;
+    for (int attempt = 0;; attempt++) {
+        if ((rc = grow(c->d_stream, c->cap_stream, (size_t)stream_cap))) return rc;
+        if ((rc = grow(c->d_pe_work, c->cap_pe_work, (size_t)stream_cap))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_used, 0, sizeof(unsigned long long), s));
+        rc = launch_align(c, c->d_bases, nbases, c->d_reads, n, nstale ? c->d_stales : nullptr, nstale, max_len, BASAL_STREAM_ALL, c->d_results, c->d_stream, stream_cap, c->d_used,
+                          carry ? (const uint8_t(*)[2])carry : zero_carry, s);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (used <= stream_cap) break;
+        if (attempt > 3) { g_err = "align_pairs_batch: hit stream keeps overflowing"; return BASAL_EOVERFLOW; }
+        stream_cap = used + used / 8 + 4096;
+    }
+    {
+        unsigned int guard[24];
+        HIP_TRY(hipMemcpyAsync(guard, c->d_counter + 1, sizeof guard, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, sizeof guard, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (int gr = report_guard(guard)) return gr;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_pe_misc, 0, 16 * sizeof(unsigned long long), s));
+    rc = basal_pe_enqueue(c, c->d_reads, c->d_results, c->d_stream, c->d_pe_work, npairs, c->d_pe_pairs, c->d_pe_recs, recs_cap, c->d_pe_misc, c->d_pe_misc + 1, s);
+    if (rc) return rc;
+    unsigned long long misc[16];
+    HIP_TRY(hipMemcpyAsync(misc, c->d_pe_misc, sizeof misc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pairs_out, c->d_pe_pairs, (size_t)npairs * sizeof(basal_pe_pair), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *recs_used = misc[0];
+    if (misc[0] > recs_cap) { g_err = "align_pairs_batch: record array too small; needed " + std::to_string(misc[0]); return BASAL_EOVERFLOW; }
+    if (misc[0]) HIP_TRY(hipMemcpy(recs_out, c->d_pe_recs, (size_t)misc[0] * sizeof(basal_pe_rec), hipMemcpyDeviceToHost));
+    if (stats) {
+        const unsigned int *st = (const unsigned int *)(misc + 1);
+        for (int k = 0; k < 9; k++) stats[k] += st[k];
+    }
+    // carry: the start offset after the last aligned read of each slot (basal_core_align_batch's rule), from the results on the device
+    if (carry) {
+        std::vector<basal_result> tail;
+        for (int slot = 0; slot < 2; slot++)
+            for (uint32_t i = n; i-- > 0;) {
+                const basal_read &r = reads[i];
+                const uint32_t rs = r.readset & 0x7fu;
+                if (r.len == 0 || (rs == 2 ? 1 : 0) != slot) continue;
+                basal_result one;
+                HIP_TRY(hipMemcpy(&one, c->d_results + i, sizeof one, hipMemcpyDeviceToHost));
+                if (one.status == BASAL_READ_SKIPPED) continue;
+                const bool f0 = (c->p.chains == 1) || ((c->p.chains <= 1) == (rs < 2)), f1 = (c->p.chains == 1) || ((c->p.chains <= 1) == (rs == 2));
+                if (f0) carry[slot][0] = one.start_off[0];
+                if (f1) carry[slot][1] = one.start_off[1];
+                break;
+            }
+    }
+    return BASAL_OK;
 }

@@ -35,6 +35,11 @@ struct basal_core {
     hipStream_t stream = nullptr, last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false, timed = false;
+    // paired-end pairing on the device (basal_pe.hip)
+    basal_pe_pair *d_pe_pairs = nullptr; size_t cap_pe_pairs = 0;
+    basal_pe_rec *d_pe_recs = nullptr; size_t cap_pe_recs = 0;
+    basal_hit *d_pe_work = nullptr; size_t cap_pe_work = 0;
+    unsigned long long *d_pe_misc = nullptr;  // [0] records used, then nine 32-bit statistics
     // contig names for the device-side SAM writer (basal_core_set_contig_names)
     char *d_names = nullptr;
     uint32_t *d_name_off = nullptr;
@@ -55,6 +60,8 @@ int basal_launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, 
 int basal_launch_align_carry(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
                              uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2],
                              hipStream_t s, const basal_align_extra *ex);
+int basal_pe_enqueue(basal_core *c, const void *d_reads, const void *d_results, const void *d_stream, void *d_work, uint32_t npairs, void *d_pairs, void *d_recs,
+                     uint64_t recs_cap, void *d_recs_used, void *d_stats, hipStream_t s);
 int basal_ensure_launch_geometry(basal_core *c);  // sizes c->grid (largest grid any instantiation uses) and the core's own scratch
 int basal_report_guard(const unsigned int *guard);  // BASAL_OK, or BASAL_EDEVICE + message if the kernel's bounds ledger is not clean
 

@@ -742,6 +742,9 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
     std::vector<basal_stale> stales;
     basal_stale_tracker_t *tracker = basal_host_stale_new(&P);
     uint8_t carry[2][2] = {{0, 0}, {0, 0}};
+    const bool device_pairing = al.multi == nullptr && !getenv("BASAL_PE_HOST_PAIRING");
+    std::vector<basal_pe_pair> pe_pairs;
+    std::vector<basal_pe_rec> pe_recs;
     for (;;) {
         // a batch's bases must stay below 4 GiB (32-bit offsets): the base budget closes a batch early
         int n1 = load_batch(ra, P, cli.read_end, batch / 2 + 1, 1, ra_, (size_t)1800 << 20);
@@ -782,6 +785,44 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
                     stales.push_back(se);
                 }
             }
+        }
+        if (device_pairing) {
+            // one GPU: the pairing rounds run on the device too (basal_pe.hip); what comes back is the list of records to print
+            pe_pairs.resize(np);
+            uint64_t cap = pe_recs.size() > 2 * np + 4096 ? pe_recs.size() : 2 * np + 4096, used = 0;
+            double g0 = now();
+            uint32_t st9[9] = {0};
+            for (;;) {
+                pe_recs.resize(cap);
+                uint8_t cy[2][2];
+                memcpy(cy, carry, 4);
+                memset(st9, 0, sizeof st9);
+                int rc = basal_core_align_pairs_batch(al.core, bases.data(), bases.size(), descs.data(), (uint32_t)np, stales.data(), (uint32_t)stales.size(), pe_pairs.data(),
+                                                      pe_recs.data(), cap, &used, st9, cy);
+                if (rc == BASAL_EOVERFLOW) { cap = used + used / 8 + 4096; continue; }
+                if (rc) die(std::string("align_pairs_batch: ") + basal_last_error());
+                memcpy(carry, cy, 4);
+                break;
+            }
+            for (int k = 0; k < 9; k++) pst[k] += st9[k];
+            t_gpu += now() - g0;
+            std::vector<std::string> chunks((size_t)std::max(threads, 1));
+            parallel_for(np, threads, [&](size_t b, size_t e, int tid) {
+                std::vector<char> line(1 << 16);
+                for (size_t i = b; i < e; i++) {
+                    basal_mate ma{ra_[i].name.c_str(), ra_[i].seq.data(), ra_[i].qual.data(), 1, ra_[i].index, ra_[i].max_snp, ra_[i].qc_failed, nullptr};
+                    basal_mate mb{rb_[i].name.c_str(), rb_[i].seq.data(), rb_[i].qual.data(), 2, rb_[i].index, rb_[i].max_snp, rb_[i].qc_failed, nullptr};
+                    if (pe_pairs[i].status) die("align_pairs_batch: a pair's records did not fit");
+                    size_t need = 8192 + (size_t)(pe_pairs[i].n + 2) * (2048 + 2 * (ra_[i].seq.size() + rb_[i].seq.size()));
+                    if (line.size() < need) line.resize(need);
+                    int64_t w = basal_host_format_pe_records(&P, R, &ma, &mb, pe_recs.data() + pe_pairs[i].first, pe_pairs[i].n, line.data(), line.size());
+                    if (w < 0) die(std::string("format_pe_records: ") + basal_last_error());
+                    chunks[(size_t)tid].append(line.data(), (size_t)w);
+                }
+            });
+            for (auto &c : chunks) out.write(c.data(), c.size());
+            n_pairs += np;
+            continue;
         }
         results.assign(2 * np, basal_result{});
         uint64_t cap = 16 * np + 4096, used = 0;

@@ -188,6 +188,23 @@ extern "C" int basal_host_fix_pair_names(char *a, char *b) {
     return 0;
 }
 
+extern "C" int64_t basal_host_format_pe_records(const basal_params *p, const basal_ref_t *r, const basal_mate *ma_, const basal_mate *mb_, const basal_pe_rec *recs,
+                                                uint32_t n, char *out, size_t cap) {
+    Buf o{out, cap, 0, true};
+    Mate A, B;
+    load_mate(A, ma_, p);
+    load_mate(B, mb_, p);
+    for (uint32_t k = 0; k < n; k++) {
+        const basal_pe_rec &e = recs[k];
+        if (e.kind == BASAL_PE_PAIR) {
+            PairHit pp{e.chain_a, e.na, (uint32_t)e.mb, e.insert, e.ha, e.hb};
+            out_pair(o, p, r, A, B, pp, e.ma);
+        } else out_unpair(o, p, r, e.side ? B : A, e.chain_a, e.chain_b, e.ma, e.na, e.ha, e.mb, e.hb);
+    }
+    if (!o.ok) { set_error("format_pe_records: output buffer too small"); return BASAL_EOVERFLOW; }
+    return (int64_t)o.n;
+}
+
 extern "C" int64_t basal_host_format_pe(const basal_params *p, const basal_ref_t *r, const basal_mate *ma_, const basal_mate *mb_, const basal_hit *stream,
                                         char *out, size_t cap, uint32_t stats[9]) {
     Buf o{out, cap, 0, true};

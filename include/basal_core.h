@@ -261,6 +261,34 @@ int basal_pipe_rewind(basal_pipe_t *p);
  * (text form: records from read_end on are ignored). Only with nothing in flight. */
 int basal_pipe_set_read_range(basal_pipe_t *p, uint32_t next_index, uint32_t read_end);
 
+/* ---- paired-end pairing on the device ----
+ * PairAlign::RunAlign's pairing rounds (SortHits4PE + GetPairs, pairs.cpp:29-177) and the choices of StringAlignPair / StringAlignUnpair
+ * (pairs.cpp:204-305) run on the GPU over the mates' mode-tagged hit logs; what comes back is, per read pair, the list of records to
+ * print, in order.  The host turns them into text (basal_host_format_pe_records = s_OutHitPair / s_OutHitUnpair, pairs.cpp:307-485). */
+#define BASAL_PE_PAIR 0   /* one pair: both mates' lines (s_OutHitPair) */
+#define BASAL_PE_UNPAIR 1 /* one line of one mate (s_OutHitUnpair) */
+typedef struct basal_pe_rec {
+    uint8_t kind;     /* BASAL_PE_* */
+    uint8_t side;     /* UNPAIR: 0 = the line is mate 1's, 1 = mate 2's */
+    uint8_t chain_a;  /* PAIR: pairhit.chain; UNPAIR: chain of the printed mate's hit */
+    uint8_t chain_b;  /* UNPAIR: chain of the other mate's hit */
+    int32_t ma;       /* PAIR: number of pairs at the best level (the n of s_OutHitPair); UNPAIR: hits of the printed mate (-1 failed QC, 0 none) */
+    uint32_t na;      /* mismatch level of mate 1's hit (PAIR) / of the printed mate's hit (UNPAIR) */
+    int32_t mb;       /* PAIR: mismatch level of mate 2's hit; UNPAIR: hits of the other mate as StringAlignUnpair passes them (<= 0: none to point at) */
+    uint32_t insert;  /* PAIR: insert size */
+    basal_hit ha, hb; /* PAIR: mate 1's and mate 2's hit; UNPAIR: the printed mate's hit and the other mate's */
+} basal_pe_rec;
+typedef struct basal_pe_pair {
+    uint32_t first, n; /* this pair's records in the record array */
+    uint32_t status;   /* BASAL_READ_OVERFLOW: the hit stream or the record array was too small */
+} basal_pe_pair;
+/* Align the 2 * npairs mates of a batch (interleaved a0, b0, a1, b1, ...; mates that both passed QC carry BASAL_READ_ALLMODES, as for
+ * basal_host_format_pe) and pair them, all on the device; pairs_out[npairs], recs_out[recs_cap]. stats[9] is incremented: aligned /
+ * unique / multiple for pairs, mate 1, mate 2. BASAL_EOVERFLOW: *recs_used says how many records are needed. */
+int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t npairs, const basal_stale *stales,
+                                 uint32_t nstale, basal_pe_pair *pairs_out, basal_pe_rec *recs_out, uint64_t recs_cap, uint64_t *recs_used, uint32_t stats[9],
+                                 uint8_t carry[2][2]);
+
 /* ---- several GPUs of one node: reads sharded by read number, hit records gathered with RCCL ----
  * The reference fans batches out to host threads (main.cpp:60-92); this fans the reads of a batch out to GPUs. Every GPU holds the whole
  * reference + index, aligns a contiguous range of the batch's reads, and ONE ncclGather per batch moves the 32-byte records to GPU 0. */
@@ -346,6 +374,9 @@ typedef struct basal_mate {
 } basal_mate;
 int64_t basal_host_format_pe(const basal_params *p, const basal_ref_t *r, const basal_mate *a, const basal_mate *b,
                              const basal_hit *stream, char *out, size_t cap, uint32_t stats[9]);
+/* The text of one pair from the device's records (basal_core_align_pairs_batch): only name / seq / qual / readset of the mates are read. */
+int64_t basal_host_format_pe_records(const basal_params *p, const basal_ref_t *r, const basal_mate *a, const basal_mate *b, const basal_pe_rec *recs,
+                                     uint32_t n, char *out, size_t cap);
 /* FixPairReadName: truncates both names in place to their common prefix up to its last digit; -1 if they share nothing */
 int basal_host_fix_pair_names(char *name_a, char *name_b);
 
