@@ -110,6 +110,7 @@ SYMBOLS = [
     ("basal_core_sync_check", _i, [_vp]),
     ("basal_core_set_timing", _i, [_vp, _i]),
     ("basal_core_last_kernel_ms", C.c_float, [_vp]),
+    ("basal_core_last_pair_ms", C.c_float, [_vp]),
     ("basal_core_launch_info", _i, [_vp, _P(_u32), _P(_u32), _P(_u32)]),
     ("basal_last_error", C.c_char_p, []),
     ("basal_core_set_contig_names", _i, [_vp, _P(C.c_char_p), _u32]),

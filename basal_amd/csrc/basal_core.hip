@@ -1502,6 +1502,8 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->ev3) hipEventDestroy(c->ev3);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1590,6 +1592,13 @@ static int ensure_launch_geometry(basal_core *c) {
     c->grid = cus * 8;  // scratch for the largest grid any instantiation uses (8 blocks of 4 waves per CU)
     HIP_TRY(hipMalloc(&c->d_scratch, (size_t)c->grid * 4 * c->scratch_per_wave * sizeof(basal_hit)));
     return BASAL_OK;
+}
+
+extern "C" float basal_core_last_pair_ms(basal_core_t *c) {
+    if (!c || !c->pair_timed) return 0.f;
+    float ms = 0.f;
+    if (hipEventSynchronize(c->ev3) != hipSuccess || hipEventElapsedTime(&ms, c->ev2, c->ev3) != hipSuccess) return 0.f;
+    return ms;
 }
 
 extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_t *threads, uint32_t *lds_bytes) {
@@ -1903,8 +1912,10 @@ extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *base
         if (int gr = report_guard(guard)) return gr;
     }
     HIP_TRY(hipMemsetAsync(c->d_pe_misc, 0, 16 * sizeof(unsigned long long), s));
+    if (c->timing) { if (!c->ev2) { HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3)); } HIP_TRY(hipEventRecord(c->ev2, s)); }
     rc = basal_pe_enqueue(c, c->d_reads, c->d_results, c->d_stream, c->d_pe_work, npairs, c->d_pe_pairs, c->d_pe_recs, recs_cap, c->d_pe_misc, c->d_pe_misc + 1, s);
     if (rc) return rc;
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev3, s)); c->pair_timed = true; }
     unsigned long long misc[16];
     HIP_TRY(hipMemcpyAsync(misc, c->d_pe_misc, sizeof misc, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(pairs_out, c->d_pe_pairs, (size_t)npairs * sizeof(basal_pe_pair), hipMemcpyDeviceToHost, s));

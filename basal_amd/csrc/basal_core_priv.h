@@ -33,8 +33,8 @@ struct basal_core {
     basal_hit *d_stream = nullptr; size_t cap_stream = 0;
     unsigned long long *d_used = nullptr;
     hipStream_t stream = nullptr, last_stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timing = false, timed = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // around the align launch; around the pairing kernel
+    bool timing = false, timed = false, pair_timed = false;
     // paired-end pairing on the device (basal_pe.hip)
     basal_pe_pair *d_pe_pairs = nullptr; size_t cap_pe_pairs = 0;
     basal_pe_rec *d_pe_recs = nullptr; size_t cap_pe_recs = 0;

@@ -114,6 +114,88 @@ def time_reference(rule, gap, extra_flags, read_kw, read_len, n_reads, cores, de
         shutil.rmtree(d, ignore_errors=True)
 
 
+def bench_pairs(args):
+    """BASELINE.json config 3: synthetic 150 bp read pairs, -M A:G, on a transcriptome-sized stand-in (154 Mbp, 24 contigs): both mates aligned
+    with every SnpAlign mode on the GPU, the pairing rounds on the GPU too (basal_core_align_pairs_batch), the records to print come back.
+    A step = one batch of pairs from host buffers to host records (this entry point is host-to-host; the kernel-side time is the two kernels'
+    HIP-event time).  Checked pair by pair against the CPU oracle's pairing on a sample.  One GPU."""
+    import torch
+    import basal_amd as B
+    from basal_amd import core as bc
+    import synth_gpu
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    flags = ["-M", "A:G", "-S", "1"]
+    params = B.Params("A:G", flags)
+    params.c.pairend = 1
+    L = B.lib()
+    G = synth_gpu.make_genome(params, dev, scale=0.05, seed=1, repeat_copies=2000)
+    words = [w.cpu().numpy().view(np.uint64) for w in G.words]
+    sizes = np.array(G.sizes, dtype=np.uint32)
+    core = B.Core(params, 0)
+    bc._check(L.basal_core_set_reference(core.h, words[0].ctypes.data, words[1].ctypes.data, len(words[0]), G.anchors.ctypes.data, sizes.ctypes.data,
+                                         G.rc_offsets.ctypes.data, len(sizes)), "set_reference")
+    mk = C.c_uint32()
+    blocks = np.ascontiguousarray(G.blocks)
+    bc._check(L.basal_core_build_index(core.h, blocks.ctypes.data, len(blocks), C.byref(mk)), "build_index")
+    npairs, rl = min(args.batch, 2_000_000), 150
+    PE_REC = np.dtype([("kind", "u1"), ("side", "u1"), ("chain_a", "u1"), ("chain_b", "u1"), ("ma", "<i4"), ("na", "<u4"), ("mb", "<i4"), ("insert", "<u4"),
+                       ("ha", bc.HIT_DTYPE), ("hb", bc.HIT_DTYPE)])
+    PE_PAIR = np.dtype([("first", "<u4"), ("n", "<u4"), ("status", "<u4")])
+    seq = C.create_string_buffer(b"A" * rl, rl + 2)
+    qual = C.create_string_buffer(b"I" * rl, rl + 2)
+    ms = C.c_uint32()
+    assert L.basal_host_filter_read(C.byref(params.c), seq, qual, C.byref(ms)) == 0
+    batches = []
+    for k in range(min(args.steps + args.warmup, 3)):
+        b1, b2 = synth_gpu.make_pairs(G, npairs, dev, read_len=rl, seed=40 + k)
+        hb = torch.stack([b1.view(npairs, rl), b2.view(npairs, rl)], dim=1).reshape(-1).cpu().numpy()  # a0 b0 a1 b1 ...
+        d = np.zeros(2 * npairs, bc.READ_DTYPE)
+        d["seq_off"] = np.arange(2 * npairs, dtype=np.uint64) * rl
+        d["index"] = np.repeat(np.arange(npairs, dtype=np.uint32) + k * npairs, 2)
+        d["len"], d["max_snp"], d["stale_idx"] = rl, ms.value, B.STALE_NONE
+        d["readset"] = np.tile(np.array([1 | B.READ_ALLMODES, 2 | B.READ_ALLMODES], np.uint8), npairs)
+        batches.append((hb, d))
+    pairs = np.zeros(npairs, PE_PAIR)
+    recs = np.zeros(2 * npairs + 4096, PE_REC)
+    core.set_timing(True)
+    st = (C.c_uint32 * 9)()
+
+    def step(i):
+        hb, d = batches[i % len(batches)]
+        used = C.c_uint64()
+        cy = np.zeros((2, 2), np.uint8)
+        bc._check(L.basal_core_align_pairs_batch(core.h, hb.ctypes.data, len(hb), d.ctypes.data, npairs, None, 0, pairs.ctypes.data, recs.ctypes.data, len(recs),
+                                                 C.byref(used), st, cy.ctypes.data), "align_pairs_batch")
+        return used.value
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    for k in range(9):
+        st[k] = 0
+    kms, pms = [], []
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+        kms.append(core.kernel_ms())
+        pms.append(float(L.basal_core_last_pair_ms(core.h)))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    paired = st[0] / (npairs * args.steps)
+    out = {"metric": "Mreads/s aligned (100 bp SE, -M C:T, hg38) at 1/2/4/8 GPUs; SAM bit-identical", "value": 2 * npairs * args.steps / dt / 1e6, "unit": "Mreads/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "config 3: %d k synthetic 150 bp read pairs per step, -M A:G -S 1, 154 Mbp stand-in genome (24 contigs), mates aligned with every mode + paired "
+                                  "on the GPU; host buffers in, records to print out (one synchronous batch at a time)" % (npairs // 1000),
+                      "pairs_per_step": npairs, "mpairs_per_s_host_to_host": npairs * args.steps / dt / 1e6,
+                      "mpairs_per_s_kernels": npairs / ((np.mean(kms) + np.mean(pms)) * 1e-3) / 1e6, "align_kernel_ms": float(np.mean(kms)), "pair_kernel_ms": float(np.mean(pms)),
+                      "paired_frac": paired},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "align_kernel<8,false,false> + pair_kernel",
+                        "kernel_ms": float(np.mean(kms) + np.mean(pms))},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +206,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads of the cpu_baseline / parity sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--ref-sample", type=int, default=1_600_000, help="reads the true reference binary is timed on (0 = skip; it is skipped when oracle/_ref/basal is missing)")
-    ap.add_argument("--config", default="2", choices=["2", "4", "5", "5p"],
+    ap.add_argument("--config", default="2", choices=["2", "3", "4", "5", "5p"],
                     help="BASELINE.json config whose reads and flags to use (SURVEY.md section 8d): 2 = C:T -g 0 (the bench line); 4 = A:CGT -g 2, each A to C/G/T "
                          "with p 0.3, 1 %% of the reads with a 1-2 base indel; 5 = T:- (30 %% of the reads with one T deleted), -g 0; 5p = the same reads with the "
                          "BID-seq pipeline flags -n 1 -g 3")
@@ -137,6 +219,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=100, help="read length (the headline workload is 100; 150/300 exercise the 256/480-base kernels)")
     args = ap.parse_args()
 
+    if args.config == "3":
+        if args.batch == 10_000_000:
+            args.batch = 1_000_000
+        return bench_pairs(args)
     # `python bench.py --gpus N` launched plainly: start the N ranks ourselves (children of this process, decided before
     # anything here has touched a GPU -- device_count() does not initialise HIP), wait, and leave with their exit code.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:

@@ -181,6 +181,7 @@ int basal_core_sync_check(basal_core_t *c);
  * events on the stream it ran on (0 if timing is off). */
 int basal_core_set_timing(basal_core_t *c, int on);
 float basal_core_last_kernel_ms(basal_core_t *c);
+float basal_core_last_pair_ms(basal_core_t *c); /* the pairing kernel of the last basal_core_align_pairs_batch */
 /* launch geometry actually used (blocks, threads per block, waves) for reporting */
 int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_t *threads, uint32_t *lds_bytes);
 
