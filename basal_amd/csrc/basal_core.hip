@@ -173,9 +173,31 @@ __shared__ uint32_t s_anchor[64], s_rcoff[64], s_csize[64];
 // ceil(2^16 / d) for d = 1..16: x / d == (x * s_rcp[d]) >> 16 for x < 4096
 __shared__ uint32_t s_rcp[17];
 
-struct SeedEntGap {  // GAP kernels: the read's window opposite the flank BEFORE the seed, and which of its bases lie in the read
-    uint64_t br, bm, bc, bin;
+// GAP kernels: what the stream filter needs of the read opposite one seed's flanks, as bit planes (bit i = window base i, LSB first).
+// ml/ms[X]: the read base there mismatches reference letter X (zero outside the read; N's compare as their code, as in MismatchPattern0/1);
+// vl/vs: the base is a valid one inside the read. The long window (64 bases) lies on the side of the seed with more read bases
+// (SeedEnt::side: 0 = from h+K on, 1 = the 64 bases ending at h), the short one (32 bases) on the other side, next to the seed.
+struct SeedEntPl {
+    uint64_t ml[4], vl;
+    uint32_t ms[4], vs, pad;
 };
+
+__device__ __forceinline__ uint64_t bsel(uint64_t s, uint64_t a, uint64_t b) { return (s & a) | (~s & b); }  // v_bfi_b32 x2
+__device__ __forceinline__ uint32_t bsel(uint32_t s, uint32_t a, uint32_t b) { return (s & a) | (~s & b); }
+// mismatch bitmap of a window: per base the mask of the reference letter (2 * hi + lo) that is there
+__device__ __forceinline__ uint64_t plane_mismatch(uint64_t hi, uint64_t lo, const uint64_t m[4]) { return bsel(lo, bsel(hi, m[3], m[1]), bsel(hi, m[2], m[0])); }
+__device__ __forceinline__ uint32_t plane_mismatch(uint32_t hi, uint32_t lo, const uint32_t m[4]) { return bsel(lo, bsel(hi, m[3], m[1]), bsel(hi, m[2], m[0])); }
+
+// bits [start, start + 64) of an NW-word bit string (LSB first), zero outside it
+template <int NW>
+__device__ __forceinline__ uint64_t bits64(const uint64_t *pl, int start) {
+    if (start <= -64 || start >= NW * 64) return 0;
+    if (start < 0) return pl[0] << (-start);
+    const uint32_t w = (uint32_t)start >> 6, sh = (uint32_t)start & 63;
+    uint64_t v = pl[w] >> sh;
+    if (sh && w + 1 < (uint32_t)NW) v |= pl[w + 1] << (64 - sh);
+    return v;
+}
 
 #ifndef WORK_CHUNK
 #define WORK_CHUNK 8  // reads a wave takes from the queue per atomic
@@ -186,8 +208,19 @@ struct SurvEnt {  // a gap-eligible or still-alive candidate of the stream
     uint32_t meta;  // seed entry | strand << 8 | passed the ungapped flank bound << 9 | passed the gap-side bound << 10
 };
 
+// what only the GAP kernels keep per wave (an empty base otherwise: the other kernels' LDS is full at 8 blocks per CU)
 template <int NWT, bool GAP>
-struct WaveLds {
+struct GapLds {};
+template <int NWT>
+struct GapLds<NWT, true> {
+    SeedEntPl entp[32];
+    uint64_t mmp[2][4][NWT / 2];  // per chain and reference letter, "this read base mismatches it" (1 bit per base, LSB first)
+    uint64_t valp[2][NWT / 2];    // valid base inside the read
+    SurvEnt surv[128];            // the candidates the flank tests could not rule out, in visitation order
+};
+
+template <int NWT, bool GAP>
+struct WaveLds : GapLds<NWT, GAP> {
     static constexpr int NW = NWT;
     static constexpr int MAXPOS = NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
@@ -197,8 +230,7 @@ struct WaveLds {
         SeedEnt ent[32];      // the current mode's seeds
         uint32_t cs[16][16];  // before the first mode: CountSeeds(n, start) of the chain being ordered
     };
-    SeedEntGap entg[GAP ? 32 : 1];
-    SurvEnt surv[GAP ? 128 : 1];  // GAP: the candidates the flank tests could not rule out, in visitation order
+    static constexpr bool GAPK = GAP;
     uint32_t rno[WORK_CHUNK];      // their read numbers (consecutive, or taken from the pipeline's list)
     basal_read desc[WORK_CHUNK];   // the descriptors of the chunk of reads this wave took from the queue
     basal_result res[WORK_CHUNK];  // and their results, written out together when the chunk is done
@@ -329,7 +361,7 @@ __device__ __forceinline__ basal_read uniform_read(const basal_read &v) {
 // ---- steps 1+2: pack, hash seeds, gather counts --------------------------------------------
 // pre/pre_c: the bytes of chain pre_c fetched ahead by the caller (pre_c < 0: none)
 // so0/so1: the start offsets the read inherits (they bound the seed positions that can be asked for)
-template <class LDS>
+template <bool NEWRULE, class LDS>
 __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const basal_read &rd, ReadCtx &rc, int lane, const uint32_t *pre, int pre_c,
                           uint32_t so0, uint32_t so1 PH_PARAM) {
     constexpr int NWT = LDS::NW;
@@ -373,8 +405,17 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
                 pack_codes(valid, v0, v1);
                 pack_codes(am[ch], m0, m1);
                 if (c == 0) ncnt += __popcll(ballot(pos < rc.len && !valid));
+                if constexpr (LDS::GAPK) {  // the stream filter's bit planes: this base against each reference letter (the comparison is per base)
+                    const uint64_t code = al[ch], mcode = am[ch];
+                    const bool in = pos < rc.len;
+                    const uint64_t p0 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 0) & 3)), p1 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 1) & 3)),
+                                   p2 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 2) & 3)), p3 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 3) & 3)),
+                                   pv = ballot(in && (valid & 1));
+                    if (lane0(lane)) { L.mmp[c][0][b] = p0; L.mmp[c][1][b] = p1; L.mmp[c][2][b] = p2; L.mmp[c][3][b] = p3; L.valp[c][b] = pv; }
+                }
             } else {  // past the read: what 64 lanes holding byte 0 would pack to
                 a0 = a1 = code_fill(al[0]); v0 = v1 = code_fill(rg[0]); m0 = m1 = code_fill(am[0]);
+                if constexpr (LDS::GAPK) if (b < (uint32_t)NWT / 2 && lane0(lane)) { L.mmp[c][0][b] = L.mmp[c][1][b] = L.mmp[c][2][b] = L.mmp[c][3][b] = 0; L.valp[c][b] = 0; }
             }
             if (lane0(lane)) {
                 if (2 * b < (uint32_t)NWT + 1) { L.q[c][0][2 * b] = a0; L.q[c][1][2 * b] = v0; L.q[c][2][2 * b] = m0; }
@@ -869,12 +910,12 @@ __device__ uint32_t find_kth(const HitState &st, const basal_hit *log, uint32_t 
 // candidate belongs to, its position in the list, its location and the flank word the filter compares.
 struct ChunkLoads {
     uint32_t ei, jj, loc_raw;
-    uint64_t f, fb;  // non-GAP: f = the flank word on the entry's longer side; GAP: f = after the seed, fb = before it
+    uint64_t f, fb, f2;  // non-GAP: f = the flank word on the entry's longer side; GAP: plane words after / before the seed, and the next 32 bases on the longer side
 };
 template <bool BOTH, class LDS>
 __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L, uint32_t inc, uint64_t end_mask, uint32_t tb, uint32_t T, int lane,
                                                   uint32_t nlocs_u, unsigned long long flank_b_off, uint32_t r) {
-    ChunkLoads c = {0, 0, 0, 0, 0};
+    ChunkLoads c = {0, 0, 0, 0, 0, 0};
     // which seed's list candidate t belongs to = the number of list ends (inc[e], e < nent-1) that are <= t. The chunk is
     // 64 consecutive t, so that is the count at tb plus the ends inside the chunk (one or two, typically) -- cheaper than
     // comparing every lane against every end. (A ballot of one compare is one v_cmp; of a conjunction it is
@@ -889,7 +930,7 @@ __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L
         if (jj >= e_m) jj -= e_m;
         const uint32_t x = guard_u32(cx, G_LOCS, e_off + jj, nlocs_u, r);  // kmer_off is 32-bit, so list positions are too
         c.loc_raw = cx.locs[x];
-        if (BOTH) { c.f = cx.flank_a[x]; c.fb = cx.flank_b[x]; }
+        if (BOTH) { c.f = cx.flank_a[x]; c.fb = cx.flank_a[flank_b_off + x]; c.f2 = cx.flank_a[(2ULL + (e_hcs >> 17)) * flank_b_off + x]; }
         else c.f = cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)];
         c.ei = ei;
         c.jj = jj;
@@ -957,14 +998,14 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         if (srcno < r || srcno - COLD(ghost_base) < 2u) {
             basal_read src = uniform_read(cx.reads[srcno]);
             rc.rno = r;
-            prep_read(cx, L, tab, src, rc, lane, nullptr, -1, 0, 0 PH_ARG);
+            prep_read<NEWRULE>(cx, L, tab, src, rc, lane, nullptr, -1, 0, 0 PH_ARG);
             if (rc.on(0)) so0 = best_start_offset(cx, L, rc, 0, lane, so0);
             if (rc.on(1)) so1 = best_start_offset(cx, L, rc, 1, lane, so1);
         }
     }
     rc.rno = r;
     PH(PH_ENTRY);
-    prep_read(cx, L, tab, rd, rc, lane, pre, pre_c, so0, so1 PH_ARG);
+    prep_read<NEWRULE>(cx, L, tab, rd, rc, lane, pre, pre_c, so0, so1 PH_ARG);
     if (stale) {  // seed slots past this read's own seeds still hold an earlier read's values
         if (lane < 30) {
             uint32_t c = (uint32_t)lane / 15, j = (uint32_t)lane % 15, pos = rc.npos + j;
@@ -1022,23 +1063,28 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 if (lane >= o) inc += v;
             }
         if ((uint32_t)lane < nent) {
-            // which flank of the seed has more read bases opposite it (GAP kernels test both flanks)
+            // which flank of the seed has more read bases opposite it (the window tested is 32 bases; GAP kernels: 64 there, 32 on the other side)
+            constexpr int WIN = GAP ? 64 : 32;
             int n_after = (int)rc.len - (int)(e_h + cx.K), n_before = (int)e_h;
-            n_after = n_after < 0 ? 0 : n_after > 32 ? 32 : n_after;
-            n_before = n_before > 32 ? 32 : n_before;
-            uint32_t side = GAP ? 0u : (uint32_t)(n_before > n_after);
-            int p0 = side ? (int)e_h - 32 : (int)(e_h + cx.K);
-            uint64_t wr, wm, wc;
-            plane_window3<NWT, NEWRULE>(L.q[e_chain], p0, wr, wm, wc);
+            n_after = n_after < 0 ? 0 : n_after > WIN ? WIN : n_after;
+            n_before = n_before > WIN ? WIN : n_before;
+            const uint32_t side = (uint32_t)(n_before > n_after);
+            uint64_t wr = 0, wm = 0, wc = 0;
+            if (!GAP) plane_window3<NWT, NEWRULE>(L.q[e_chain], side ? (int)e_h - 32 : (int)(e_h + cx.K), wr, wm, wc);
             SeedEnt e = {e_off, e_m, e_nfwd, e_jj0, inc - e_m, e_h | (e_chain << 16) | (side << 17), wr, wm, wc};
             L.ent[lane] = e;
-            if (GAP) {
-                int pb = (int)e_h - 32;
-                uint64_t br, bm, bc;
-                plane_window3<NWT, NEWRULE>(L.q[e_chain], pb, br, bm, bc);
-                SeedEntGap g = {br, bm, bc,
-                                n_before >= 32 ? kPairLo : (kPairLo & ((1ULL << (2 * n_before)) - 1))};  // the window's last n_before bases are read bases
-                L.entg[lane] = g;
+            if constexpr (GAP) {
+                const int pl = side ? (int)e_h - 64 : (int)(e_h + cx.K), ps = side ? (int)(e_h + cx.K) : (int)e_h - 32;
+                SeedEntPl P;
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    P.ml[x] = bits64<NWT / 2>(L.mmp[e_chain][x], pl);
+                    P.ms[x] = (uint32_t)bits64<NWT / 2>(L.mmp[e_chain][x], ps);
+                }
+                P.vl = bits64<NWT / 2>(L.valp[e_chain], pl);
+                P.vs = (uint32_t)bits64<NWT / 2>(L.valp[e_chain], ps);
+                P.pad = 0;
+                L.entp[lane] = P;
             }
         }
         wave_sync();
@@ -1053,12 +1099,12 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         const uint32_t nlocs_u = COLD(nlocs);
         const unsigned long long flank_b_off = (unsigned long long)nlocs_u + 64;  // flank_b = flank_a + nlocs + 64
         uint32_t nsurv = 0, batch = 0;
-        ChunkLoads nxt = {0, 0, 0, 0, 0};
+        ChunkLoads nxt = {0, 0, 0, 0, 0, 0};
         if (T > 0) nxt = issue_chunk<GAP>(cx, L, inc, end_mask, 0, T, lane, nlocs_u, flank_b_off, r);
         for (uint32_t t0 = 0; (t0 < T || (GAP && nsurv > 0)) && !done;) {
             uint32_t t;
             bool active;
-            if (GAP) {
+            if constexpr (GAP) {
                 if (t0 < T && nsurv < 64) {
                     const uint32_t tf = t0 + lane;
                     const bool af = tf < T;
@@ -1068,24 +1114,57 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     if (t0 + 64 < T) nxt = issue_chunk<true>(cx, L, inc, end_mask, t0 + 64, T, lane, nlocs_u, flank_b_off, r);
                     SurvEnt sv = {0, 0};
                     if (af) {
-                        // both flanks: the ungapped count is at least the two windows' mismatches; the gap search gives up at
-                        // once when the read prefix up to the seed end already holds thr-1 mismatches (MismatchPattern0's
-                        // return value vs seed_pos+seed_size, align.cpp:365; no N mask there), and the window before the seed
-                        // is part of that prefix -- so a candidate that fails both tests needs no reference access at all.
-                        // The location comes with the same round trip, so that a survivor's reference words are one more.
+                        // The candidate's reference bases around the seed came with its location, as bit planes: 64 bases on the side of the
+                        // seed that has more read bases opposite it, 32 on the other. Three bounds, none of which touches the reference:
+                        //  * the ungapped count (CountMismatch*, align.h:118-239) is at least the windows' mismatches at valid bases + the N count;
+                        //  * the gap search gives up at once when the read prefix up to the seed end holds thr-1 mismatches (MismatchPattern0's
+                        //    return value vs seed_pos+seed_size, align.cpp:365; no N mask there): the window(s) before the seed are part of it;
+                        //  * a gapped hit at shift s (align.cpp:367-405) is a left part [0, gap_pos) at the candidate's start holding i mismatches
+                        //    and a right part of m2 bases at start+s holding j, i + j + t <= thr - 1, which together cover the read (s > 0) or
+                        //    all of it but t bases (s < 0): a base that mismatches at BOTH starts is counted in i or j wherever the gap falls, so
+                        //    i + j >= popc(D0 & Ds) over any window (minus t for s < 0).
                         const uint32_t eif = cur.ei;
                         const uint32_t e_hcs = L.ent[eif].hcs, e_nfwd = L.ent[eif].nfwd;
-                        const uint64_t e_fr = L.ent[eif].fr, e_fm = L.ent[eif].fm, e_fc = NEWRULE ? L.ent[eif].fc : 0;
-                        const SeedEntGap g = L.entg[eif];
+                        const SeedEntPl P = L.entp[eif];
+                        const bool before = (e_hcs >> 17) != 0;
                         uint32_t lc = cur.loc_raw - (e_hcs & 0xffffu);
                         if (((unsigned long long)(lc >> 5) + NWT + 4) >= COLD(nwords)) lc = (uint32_t)guard_idx(cx, G_XREF, lc, 0, r) + BASAL_REF_MARGIN * 32;
-                        const uint64_t db = cmp_word<NEWRULE>(g.br, g.bc, cur.fb), da = cmp_word<NEWRULE>(e_fr, e_fc, cur.f);
-                        const uint32_t lb = rc.n_count + XM64(da & e_fm) + XM64(db & g.bm);
+                        const uint32_t a_lo = (uint32_t)cur.f, a_hi = (uint32_t)(cur.f >> 32), b_lo = (uint32_t)cur.fb, b_hi = (uint32_t)(cur.fb >> 32);
+                        const uint32_t f_lo = (uint32_t)cur.f2, f_hi = (uint32_t)(cur.f2 >> 32);
+                        // long window: after the seed = [near | far << 32], before it = [far | near << 32] (bit i = base i of the 64)
+                        const uint64_t Llo = before ? ((uint64_t)b_lo << 32) | f_lo : ((uint64_t)f_lo << 32) | a_lo;
+                        const uint64_t Lhi = before ? ((uint64_t)b_hi << 32) | f_hi : ((uint64_t)f_hi << 32) | a_hi;
+                        const uint32_t Slo = before ? a_lo : b_lo, Shi = before ? a_hi : b_hi;
+                        const uint64_t D0l = plane_mismatch(Lhi, Llo, P.ml);
+                        const uint32_t D0s = plane_mismatch(Shi, Slo, P.ms);
+                        const uint32_t lb = rc.n_count + popc64(D0l & P.vl) + (uint32_t)__popc(D0s & P.vs);
                         const bool al = lb <= st.thr;
-                        bool gk = st.thr >= 2 && XM64(db & g.bin) < st.thr - 1;
+                        bool gk = st.thr >= 2 && (before ? popc64(D0l) : (uint32_t)__popc(D0s)) < st.thr - 1;
+                        if (gk) {
+                            gk = false;
+                            for (uint32_t tt = 1; tt <= 2 * cx.gap; tt++) {
+                                const uint32_t tg = (tt + 1) >> 1;
+                                if (st.thr < 1 + tg) break;
+                                uint64_t Dl;
+                                uint32_t Ds, lim = st.thr - 1;
+                                if (tt & 1) {  // shift -t: read base i against window base i - t
+                                    Dl = plane_mismatch(Lhi << tg, Llo << tg, P.ml) & (~0ULL << tg);
+                                    Ds = plane_mismatch(Shi << tg, Slo << tg, P.ms) & (~0u << tg);
+                                } else {  // shift +t
+                                    Dl = plane_mismatch(Lhi >> tg, Llo >> tg, P.ml) & (~0ULL >> tg);
+                                    Ds = plane_mismatch(Shi >> tg, Slo >> tg, P.ms) & (~0u >> tg);
+                                    lim -= tg;
+                                }
+                                gk |= popc64(D0l & Dl) + (uint32_t)__popc(D0s & Ds) <= lim;
+                            }
+                        }
                         keep = al || gk;
                         sv.loc = lc;
                         sv.meta = eif | ((uint32_t)(cur.jj >= e_nfwd) << 8) | ((uint32_t)al << 9) | ((uint32_t)gk << 10);
+#ifdef BASAL_CHECK_FILTER  // diagnostic build (`make chk`): every candidate is scored exactly, and one the bounds would have dropped must not be accepted
+                        sv.meta = eif | ((uint32_t)(cur.jj >= e_nfwd) << 8) | (1u << 9) | ((uint32_t)(st.thr >= 2) << 10) | ((uint32_t)al << 11) | ((uint32_t)gk << 12);
+                        keep = true;
+#endif
                     }
                     PH(PH_FILTER);
                     uint64_t mk = ballot(keep);
@@ -1112,13 +1191,19 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             // Non-GAP: the chunk is 64 consecutive t, so that is the count at t0 plus the ends inside the chunk (one
             // or two, typically) -- cheaper than comparing every lane against every end.
             uint32_t ei = 0, loc = 0, strand = 0, mm = 0xffff, hcs = 0;
+#ifdef BASAL_CHECK_FILTER
+            uint32_t chk = 3;
+#endif
             bool gap_ok = false;  // GAP: the flank tests leave the gap search a chance
             uint64_t W[GAP ? NWT + 2 : 1], D0[GAP ? NWT : 1];  // GAP: the candidate's reference words and ungapped mismatch bitmap
             uint32_t rel0 = 0;
-            if (GAP) {
+            if constexpr (GAP) {
                 // one round trip fetches the reference words of all 2g+1 start positions; the ungapped count (the bitmap under
                 // the valid mask, plus the N count) and the gap search both work from these registers
                 bool alive = false;
+#ifdef BASAL_CHECK_FILTER
+                chk = active ? (L.surv[lane].meta >> 11) & 3u : 3u;
+#endif
                 if (active) {
                     const SurvEnt sv = L.surv[lane];
                     ei = sv.meta & 0xff;
@@ -1178,6 +1263,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 }
             } else q = L.q[(hcs >> 16) & 1];
             PH(PH_SCORE);
+#ifdef BASAL_CHECK_FILTER
+            if (GAP && active && mm <= st.thr && !(chk & 1)) guard_idx(cx, G_WATCHDOG, 0x20000u | mm, 0, r);
+#endif
             uint64_t act = ballot(active);
             uint64_t ung_pending = act, gap_pending = GAP ? (act & ballot(gap_ok)) : 0;
             bool gfound = false;
@@ -1189,6 +1277,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     bool mine = (gap_pending >> lane) & 1;
                     gfound = false;
                     if (mine) gfound = gap_align<NWT, NEWRULE>(cx, W, rel0, D0, q, rc, st.thr, hcs & 0xffffu, gsnp, gpos, gshift);
+#ifdef BASAL_CHECK_FILTER
+                    if (gfound && !(chk & 2)) guard_idx(cx, G_WATCHDOG, 0x30000u | (gsnp << 8) | (uint32_t)(gshift & 0xff), 0, r);
+#endif
                 }
                 uint64_t acc = ballot(mm <= st.thr) & ung_pending;  // ung_pending holds active lanes only
                 uint64_t gm = GAP ? (ballot(gfound) & gap_pending) : 0;
@@ -1226,7 +1317,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 if (!recompute || done) break;
             }
             PH(PH_REPLAY);
-            if (GAP) {  // drop the processed batch from the front of the list
+            if constexpr (GAP) {  // drop the processed batch from the front of the list
                 uint32_t rest = nsurv - batch;
                 SurvEnt v = {0, 0};
                 if ((uint32_t)lane < rest) v = L.surv[batch + lane];

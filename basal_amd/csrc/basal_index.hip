@@ -115,6 +115,49 @@ __global__ __launch_bounds__(256) void fill_flanks_sorted(const uint64_t *__rest
     }
 }
 
+// ---- GAP cores (-g > 0): the flanks as BIT PLANES, 64 bases each side ----------------------------------------------------------------------
+// The gap search (GapAlign, align.cpp:348-410) accepts a candidate when a left part at the candidate's own start and a right part shifted by
+// up to g bases cover the read with few mismatches; a lower bound of that needs the candidate's reference bases at every shift. Kept as the
+// two bit planes of the base codes (u64 = high-bit plane << 32 | low-bit plane, bit i = base i of the window, LSB first), a shift of the
+// window is a shift of two words, and the exact mismatch bitmap against the read is three bit-selects (v_bfi) of four per-read "mismatches
+// letter X here" masks. Four words per entry: bases [e+K, e+K+32), [e-32, e), [e+K+32, e+K+64), [e-64, e-32) of the entry's strand.
+__device__ __forceinline__ uint32_t even_bits(uint64_t x) {  // bit 2j of x -> bit j
+    x &= 0x5555555555555555ULL;
+    x = (x | (x >> 1)) & 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffULL;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffULL;
+    return (uint32_t)(x | (x >> 16));
+}
+__device__ __forceinline__ uint64_t plane_word(const uint64_t *__restrict__ x, uint32_t p) {
+    const uint32_t a = (p & 31) * 2;
+    const uint64_t *w = x + (p >> 5);
+    const uint64_t v = a ? (w[0] << a) | (w[1] >> (64 - a)) : w[0];  // base j at bits 63-2j (high), 62-2j (low)
+    const uint64_t rv = __brevll(v);                                  // base j: high bit at 2j, low bit at 2j+1
+    return ((uint64_t)even_bits(rv) << 32) | even_bits(rv >> 1);
+}
+__device__ __forceinline__ void store_planes(const uint64_t *__restrict__ x, uint32_t g, uint32_t K, unsigned long long i, unsigned long long stride,
+                                             uint64_t *__restrict__ pl) {
+    pl[i] = plane_word(x, g + K);
+    pl[stride + i] = plane_word(x, g - 32);
+    pl[2 * stride + i] = plane_word(x, g + K + 32);
+    pl[3 * stride + i] = plane_word(x, g - 64);
+}
+__global__ __launch_bounds__(256) void fill_planes(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const uint32_t *__restrict__ koff,
+                                                   const uint32_t *__restrict__ knfwd, const uint32_t *__restrict__ locs, uint32_t total_kmers, uint32_t K,
+                                                   unsigned long long stride, uint64_t *__restrict__ pl) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total_kmers) return;
+    uint32_t b = koff[k], e = koff[k + 1], nf = knfwd[k];
+    for (uint32_t i = b; i < e; i++) store_planes((i - b) >= nf ? xr : xf, locs[i], K, i, stride, pl);
+}
+__global__ __launch_bounds__(256) void fill_planes_sorted(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const uint32_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ locs, unsigned long long nlocs, uint32_t K, unsigned long long stride,
+                                                          uint64_t *__restrict__ pl) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nlocs; i += (unsigned long long)gridDim.x * blockDim.x)
+        store_planes((keys[i] & 1u) ? xr : xf, locs[i], K, i, stride, pl);
+}
+
 }  // namespace
 
 // d_sorted_keys: the GPU build's sorted (2 * kmer + strand) keys, entry for entry with d_locs; nullptr after set_index (host-built arrays)
@@ -122,8 +165,24 @@ int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys) {
     // one allocation, the "before" words right behind the "after" words: the kernel picks one by adding nlocs + 64 to the index
     hipFree(c->d_flank_a);
     c->d_flank_a = c->d_flank_b = nullptr;
-    HIP_TRYI(hipMalloc(&c->d_flank_a, 2 * (c->nlocs + 64) * 8));
-    c->d_flank_b = c->d_flank_a + (c->nlocs + 64);
+    const unsigned long long stride = c->nlocs + 64;
+    if (c->p.gap > 0) {  // the GAP kernels read bit planes, four words per entry (see fill_planes); the others never look at them
+        HIP_TRYI(hipMalloc(&c->d_flank_a, 4 * stride * 8));
+        c->d_flank_b = c->d_flank_a + stride;
+        if (d_sorted_keys && c->nlocs) {
+            unsigned long long want = (c->nlocs + 255) / 256;
+            uint32_t grid = (uint32_t)std::min<unsigned long long>(want, (unsigned long long)c->prop.multiProcessorCount * 64);
+            hipLaunchKernelGGL(fill_planes_sorted, dim3(grid), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], d_sorted_keys, c->d_locs,
+                               (unsigned long long)c->nlocs, c->p.seed_size, stride, c->d_flank_a);
+        } else
+            hipLaunchKernelGGL(fill_planes, dim3((c->total_kmers + 255) / 256), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], c->d_koff, c->d_knfwd, c->d_locs,
+                               c->total_kmers, c->p.seed_size, stride, c->d_flank_a);
+        HIP_TRYI(hipGetLastError());
+        HIP_TRYI(hipDeviceSynchronize());
+        return BASAL_OK;
+    }
+    HIP_TRYI(hipMalloc(&c->d_flank_a, 2 * stride * 8));
+    c->d_flank_b = c->d_flank_a + stride;
     if (d_sorted_keys && c->nlocs) {
         unsigned long long want = (c->nlocs + 255) / 256;
         uint32_t grid = (uint32_t)std::min<unsigned long long>(want, (unsigned long long)c->prop.multiProcessorCount * 64);

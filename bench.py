@@ -104,9 +104,10 @@ def time_reference(rule, gap, extra_flags, read_kw, read_len, n_reads, cores, de
         t_full = min(wall([]) for _ in range(2))
         secs = max(t_full - t_idle, 1e-3)
         return {"value": n_reads / secs / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "reference",
-                "sample": "the unmodified reference binary (oracle/_ref/basal -p %d) on %d reads of the same kind on a density-equivalent down-scaled genome "
-                          "(50 Mbp" + (" with the same repeat landscape" if realistic else "") + ", -s 12: ~40 index entries per seed as on 3.09 Gbp at -s 16); align time = wall %.2f s minus %.2f s of the same command with -E 0 "
-                          "(load + index build); %.0f CPU-seconds of alignment" % (cores, n_reads, t_full, t_idle, secs * cores)}
+                "sample": ("the unmodified reference binary (oracle/_ref/basal -p %d) on %d reads of the same kind on a density-equivalent down-scaled genome "
+                           "(50 Mbp" + (" with the same repeat landscape" if realistic else "") + ", -s 12: ~40 index entries per seed as on 3.09 Gbp at -s 16); "
+                           "align time = wall %.2f s minus %.2f s of the same command with -E 0 (load + index build); %.0f CPU-seconds of alignment")
+                          % (cores, n_reads, t_full, t_idle, secs * cores)}
     except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
         log("reference timing failed: %r" % (e,))
         return None
