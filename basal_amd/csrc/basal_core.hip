@@ -1131,31 +1131,30 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         if (((unsigned long long)(lc >> 5) + NWT + 4) >= COLD(nwords)) lc = (uint32_t)guard_idx(cx, G_XREF, lc, 0, r) + BASAL_REF_MARGIN * 32;
                         const uint32_t a_lo = (uint32_t)cur.f, a_hi = (uint32_t)(cur.f >> 32), b_lo = (uint32_t)cur.fb, b_hi = (uint32_t)(cur.fb >> 32);
                         const uint32_t f_lo = (uint32_t)cur.f2, f_hi = (uint32_t)(cur.f2 >> 32);
-                        // long window: after the seed = [near | far << 32], before it = [far | near << 32] (bit i = base i of the 64)
-                        const uint64_t Llo = before ? ((uint64_t)b_lo << 32) | f_lo : ((uint64_t)f_lo << 32) | a_lo;
-                        const uint64_t Lhi = before ? ((uint64_t)b_hi << 32) | f_hi : ((uint64_t)f_hi << 32) | a_hi;
-                        const uint32_t Slo = before ? a_lo : b_lo, Shi = before ? a_hi : b_hi;
+                        // long window: after the seed = [near | far << 32], before it = [far | near << 32] (bit i = base i of the 64); selects, not branches
+                        const uint32_t bm = 0u - (uint32_t)before;
+                        const uint64_t Llo = ((uint64_t)bsel(bm, b_lo, f_lo) << 32) | bsel(bm, f_lo, a_lo);
+                        const uint64_t Lhi = ((uint64_t)bsel(bm, b_hi, f_hi) << 32) | bsel(bm, f_hi, a_hi);
+                        const uint32_t Slo = bsel(bm, a_lo, b_lo), Shi = bsel(bm, a_hi, b_hi);
                         const uint64_t D0l = plane_mismatch(Lhi, Llo, P.ml);
                         const uint32_t D0s = plane_mismatch(Shi, Slo, P.ms);
                         const uint32_t lb = rc.n_count + popc64(D0l & P.vl) + (uint32_t)__popc(D0s & P.vs);
                         const bool al = lb <= st.thr;
-                        bool gk = st.thr >= 2 && (before ? popc64(D0l) : (uint32_t)__popc(D0s)) < st.thr - 1;
-                        if (gk) {
-                            gk = false;
-                            for (uint32_t tt = 1; tt <= 2 * cx.gap; tt++) {
-                                const uint32_t tg = (tt + 1) >> 1;
-                                if (st.thr < 1 + tg) break;
-                                uint64_t Dl;
-                                uint32_t Ds, lim = st.thr - 1;
-                                if (tt & 1) {  // shift -t: read base i against window base i - t
-                                    Dl = plane_mismatch(Lhi << tg, Llo << tg, P.ml) & (~0ULL << tg);
-                                    Ds = plane_mismatch(Shi << tg, Slo << tg, P.ms) & (~0u << tg);
-                                } else {  // shift +t
-                                    Dl = plane_mismatch(Lhi >> tg, Llo >> tg, P.ml) & (~0ULL >> tg);
-                                    Ds = plane_mismatch(Shi >> tg, Slo >> tg, P.ms) & (~0u >> tg);
-                                    lim -= tg;
-                                }
-                                gk |= popc64(D0l & Dl) + (uint32_t)__popc(D0s & Ds) <= lim;
+                        const uint32_t pre_mm = bsel(bm, popc64(D0l), (uint32_t)__popc(D0s));
+                        bool gk = false;
+                        // (the lanes of a chunk mostly share one seed, hence one window geometry: where the prefix test fails it fails for the whole wave)
+                        if (st.thr >= 2 && pre_mm < st.thr - 1)
+#pragma unroll
+                        for (uint32_t tg = 1; tg <= BASAL_MAXGAPS; tg++) {  // tt = 2 tg - 1 (shift -tg), then tt = 2 tg (shift +tg); wave-uniform conditions
+                            if (tg <= cx.gap && st.thr >= 1 + tg) {
+                                // shift -t: read base i against window base i - t
+                                const uint64_t Dm = plane_mismatch(Lhi << tg, Llo << tg, P.ml) & (~0ULL << tg);
+                                const uint32_t dm = plane_mismatch(Shi << tg, Slo << tg, P.ms) & (~0u << tg);
+                                gk |= popc64(D0l & Dm) + (uint32_t)__popc(D0s & dm) <= st.thr - 1;
+                                // shift +t
+                                const uint64_t Dp = plane_mismatch(Lhi >> tg, Llo >> tg, P.ml) & (~0ULL >> tg);
+                                const uint32_t dp = plane_mismatch(Shi >> tg, Slo >> tg, P.ms) & (~0u >> tg);
+                                gk |= popc64(D0l & Dp) + (uint32_t)__popc(D0s & dp) <= st.thr - 1 - tg;
                             }
                         }
                         keep = al || gk;
