@@ -130,13 +130,15 @@ __device__ __forceinline__ uint32_t guard_u32(const DevCtx &cx, int kind, uint32
     return (uint32_t)guard_idx(cx, kind, idx, lim, r);
 }
 
-struct SeedEnt {  // one (chain, phase) seed of the current mode
+struct SeedEntBase {  // one (chain, phase) seed of the current mode
     uint32_t off, m, nfwd, jj0, pre;  // pre = number of candidates before this seed in the mode's stream
     uint32_t hcs;                     // h | chain << 16 | side << 17; side: 0 = test the flank after the seed, 1 = the one before it
+};
+template <bool GAP>
+struct SeedEntT : SeedEntBase {};  // GAP kernels keep their windows as bit planes (SeedEntPl)
+template <>
+struct SeedEntT<false> : SeedEntBase {
     uint64_t fr, fm, fc;              // the read's bases / valid mask / convert-to plane opposite that flank
-    __device__ __forceinline__ uint32_t h() const { return hcs & 0xffffu; }
-    __device__ __forceinline__ uint32_t chain() const { return (hcs >> 16) & 1u; }
-    __device__ __forceinline__ uint32_t side() const { return hcs >> 17; }
 };
 
 // 32 read bases starting at read position p (may be negative or run past the read: those bases come
@@ -188,15 +190,13 @@ __device__ __forceinline__ uint32_t bsel(uint32_t s, uint32_t a, uint32_t b) { r
 __device__ __forceinline__ uint64_t plane_mismatch(uint64_t hi, uint64_t lo, const uint64_t m[4]) { return bsel(lo, bsel(hi, m[3], m[1]), bsel(hi, m[2], m[0])); }
 __device__ __forceinline__ uint32_t plane_mismatch(uint32_t hi, uint32_t lo, const uint32_t m[4]) { return bsel(lo, bsel(hi, m[3], m[1]), bsel(hi, m[2], m[0])); }
 
-// bits [start, start + 64) of an NW-word bit string (LSB first), zero outside it
+// bits [start, start + 64) of an NW-word bit string (LSB first) kept as pl[1..NW] between two zero words; zero outside it
 template <int NW>
 __device__ __forceinline__ uint64_t bits64(const uint64_t *pl, int start) {
-    if (start <= -64 || start >= NW * 64) return 0;
-    if (start < 0) return pl[0] << (-start);
-    const uint32_t w = (uint32_t)start >> 6, sh = (uint32_t)start & 63;
-    uint64_t v = pl[w] >> sh;
-    if (sh && w + 1 < (uint32_t)NW) v |= pl[w + 1] << (64 - sh);
-    return v;
+    int s = start + 64;
+    s = s < 0 ? 0 : s > (NW + 1) * 64 - 1 ? (NW + 1) * 64 - 1 : s;  // a start left of -64 or right of the string: all zero either way
+    const uint32_t w = (uint32_t)s >> 6, sh = (uint32_t)s & 63;
+    return (pl[w] >> sh) | ((pl[w + 1] << 1) << (63 - sh));
 }
 
 #ifndef WORK_CHUNK
@@ -214,8 +214,10 @@ struct GapLds {};
 template <int NWT>
 struct GapLds<NWT, true> {
     SeedEntPl entp[32];
-    uint64_t mmp[2][4][NWT / 2];  // per chain and reference letter, "this read base mismatches it" (1 bit per base, LSB first)
-    uint64_t valp[2][NWT / 2];    // valid base inside the read
+    // per chain and reference letter, "this read base mismatches it" (1 bit per base, LSB first), and "valid base inside the read";
+    // a zero word on either side of the NWT/2 data words, so that a window at any position is two loads and a funnel shift, no branches
+    uint64_t mmp[2][4][NWT / 2 + 2];
+    uint64_t valp[2][NWT / 2 + 2];
     SurvEnt surv[128];            // the candidates the flank tests could not rule out, in visitation order
 };
 
@@ -227,7 +229,7 @@ struct WaveLds : GapLds<NWT, GAP> {
     uint32_t seed[2][MAXPOS];   // XT hash; bit 31: seed window contains a non-ACGT base
     uint32_t cnt[2][MAXPOS];    // index2[seed].n[0]
     union {
-        SeedEnt ent[32];      // the current mode's seeds
+        SeedEntT<GAP> ent[32];  // the current mode's seeds
         uint32_t cs[16][16];  // before the first mode: CountSeeds(n, start) of the chain being ordered
     };
     static constexpr bool GAPK = GAP;
@@ -411,11 +413,11 @@ __device__ void prep_read(const DevCtx &cx, LDS &L, const uint8_t *tab, const ba
                     const uint64_t p0 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 0) & 3)), p1 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 1) & 3)),
                                    p2 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 2) & 3)), p3 = ballot(in && (cmp_word<NEWRULE>(code, mcode, 3) & 3)),
                                    pv = ballot(in && (valid & 1));
-                    if (lane0(lane)) { L.mmp[c][0][b] = p0; L.mmp[c][1][b] = p1; L.mmp[c][2][b] = p2; L.mmp[c][3][b] = p3; L.valp[c][b] = pv; }
+                    if (lane0(lane)) { L.mmp[c][0][b + 1] = p0; L.mmp[c][1][b + 1] = p1; L.mmp[c][2][b + 1] = p2; L.mmp[c][3][b + 1] = p3; L.valp[c][b + 1] = pv; }
                 }
             } else {  // past the read: what 64 lanes holding byte 0 would pack to
                 a0 = a1 = code_fill(al[0]); v0 = v1 = code_fill(rg[0]); m0 = m1 = code_fill(am[0]);
-                if constexpr (LDS::GAPK) if (b < (uint32_t)NWT / 2 && lane0(lane)) { L.mmp[c][0][b] = L.mmp[c][1][b] = L.mmp[c][2][b] = L.mmp[c][3][b] = 0; L.valp[c][b] = 0; }
+                if constexpr (LDS::GAPK) if (b < (uint32_t)NWT / 2 && lane0(lane)) { L.mmp[c][0][b + 1] = L.mmp[c][1][b + 1] = L.mmp[c][2][b + 1] = L.mmp[c][3][b + 1] = 0; L.valp[c][b + 1] = 0; }
             }
             if (lane0(lane)) {
                 if (2 * b < (uint32_t)NWT + 1) { L.q[c][0][2 * b] = a0; L.q[c][1][2 * b] = v0; L.q[c][2][2 * b] = m0; }
@@ -852,11 +854,13 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
     const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
     if (ballot(hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key) & in_regs) return 0;
-    for (uint32_t base = 64; base < st.nlog; base += 64) {  // long logs: scan the part in memory
+    for (uint32_t base = 64; base < st.nlog; base += 256) {  // long logs: scan the part in memory, four loads in flight per round trip
         bool d = false;
-        if (base + lane < st.nlog) {
-            basal_hit h = log[base + lane];
-            d = hit_key(h.chr >> 1, h.loc, h.gap_size != 0) == key;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t idx = base + 64 * u + (uint32_t)lane;
+            const basal_hit h = log[idx < st.nlog ? idx : 0];  // (record 0 of the memory log is never written: its slot belongs to the registers)
+            d |= idx < st.nlog && hit_key(h.chr >> 1, h.loc, h.gap_size != 0) == key;
         }
         if (ballot(d)) return 0;
     }
@@ -1071,7 +1075,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             const uint32_t side = (uint32_t)(n_before > n_after);
             uint64_t wr = 0, wm = 0, wc = 0;
             if (!GAP) plane_window3<NWT, NEWRULE>(L.q[e_chain], side ? (int)e_h - 32 : (int)(e_h + cx.K), wr, wm, wc);
-            SeedEnt e = {e_off, e_m, e_nfwd, e_jj0, inc - e_m, e_h | (e_chain << 16) | (side << 17), wr, wm, wc};
+            SeedEntT<GAP> e;
+            e.off = e_off; e.m = e_m; e.nfwd = e_nfwd; e.jj0 = e_jj0; e.pre = inc - e_m; e.hcs = e_h | (e_chain << 16) | (side << 17);
+            if constexpr (!GAP) { e.fr = wr; e.fm = wm; e.fc = wc; }
             L.ent[lane] = e;
             if constexpr (GAP) {
                 const int pl = side ? (int)e_h - 64 : (int)(e_h + cx.K), ps = side ? (int)(e_h + cx.K) : (int)e_h - 32;
@@ -1228,7 +1234,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 }
             }
             const uint64_t(*q)[NWT + 1] = L.q[0];
-            if (!GAP) {
+            if constexpr (!GAP) {
                 // this chunk's location and flank word were requested one chunk ago
                 const ChunkLoads cur = nxt;
                 // the next chunk's loads go out before this one is looked at: they overlap its filter, exact scoring and replay
@@ -1394,7 +1400,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
 #define BASAL_W4NG 8
 #endif
 #ifndef BASAL_W4G
-#define BASAL_W4G 4
+#define BASAL_W4G 5  // 96 VGPRs + 104 B of scratch: +4 % over 4 waves at 128 VGPRs (configs 4 and 5p); the LDS allows no sixth block
 #endif
 #ifndef BASAL_W8NG
 #define BASAL_W8NG 5
@@ -1430,6 +1436,12 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
     if (lane <= NWT) {  // zero the pad words once
         for (int c = 0; c < 2; c++)
             for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
+    }
+    if constexpr (GAP) {
+        if (lane < 10) {  // the zero words around the bit planes: (chain, plane) = lane, plane 4 = the valid plane
+            uint64_t *pl = lane % 5 < 4 ? L.mmp[lane / 5][lane % 5] : L.valp[lane / 5];
+            pl[0] = pl[NWT / 2 + 1] = 0;
+        }
     }
     wave_sync();
     basal_hit *log = cx.scratch + (size_t)(blockIdx.x * 4 + wv) * COLD(scratch_per_wave);
