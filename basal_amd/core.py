@@ -21,7 +21,8 @@ def lib_path():
 
 def build(verbose=False):
     """Compile the HIP core and the C++ host for gfx950 (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "all"], capture_output=not verbose, text=True)
+    # `chk`: the diagnostic twin of the library that tests/test_gpu_parity.py runs the -g fixtures through (it travels prebuilt to the GPU box)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "all", "chk"], capture_output=not verbose, text=True)
     if r.returncode != 0:
         raise BasalError("building libbasal_amd.so failed:\n%s\n%s" % (r.stdout, r.stderr))
 

@@ -67,6 +67,26 @@ def test_hit_logs_match_oracle(name):
     o.close()
 
 
+def test_gap_stream_bounds_never_drop_an_accepted_candidate():
+    """The GAP kernels drop most candidates on bounds computed from the coalesced stream.  The `chk` twin of the library
+    scores EVERY candidate exactly and fails the launch when one the bounds would have dropped is accepted; every -g fixture must run clean
+    through it and still reproduce the oracle's hit logs.  (A library is loaded once per process, hence the child.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "basal_amd", "csrc"), "chk"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    gap = [n for n in H.SE if any(f == "-g" and int(H.MANIFEST[n]["flags"][i + 1]) > 0 for i, f in enumerate(H.MANIFEST[n]["flags"][:-1]))]
+    assert len(gap) >= 8, gap
+    env = dict(os.environ, BASAL_LIB=os.path.join(root, "basal_amd", "lib", "libbasal_amd_chk.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_hit_logs_match_oracle and (" + " or ".join(gap) + ")"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= len(gap), r.stdout[-500:]
+
+
 @pytest.mark.parametrize("name", H.SE)
 def test_sam_matches_golden_through_abi(name):
     flags = H.MANIFEST[name]["flags"]
