@@ -1222,7 +1222,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 const uint32_t first = loc - cx.gap;  // loc >= 12320 by construction
                 rel0 = (first & 31) + cx.gap;
                 if (active) {
-                    const uint64_t *sp = cx.xref[strand] + (first >> 5);
+                    const uint64_t *sp = (strand ? cx.xref[1] : cx.xref[0]) + (first >> 5);  // a select of two scalars, not an indexed load of the argument block
 #pragma unroll
                     for (int i = 0; i < NWT + 2; i++) W[i] = (uint32_t)i <= rc.end_element + 2 ? sp[i] : 0;
                     mismatch_map_regs<NWT, NEWRULE>(W, rel0, qg, rc.end_element, rc.end_offset, D0);
@@ -1264,7 +1264,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 if (alive) {
                     uint32_t off2 = (loc & 31) * 2;
                     uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
-                    mm = count_mismatch<NWT, NEWRULE>(cx.xref[strand] + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
+                    // (strand ? a : b selects between two scalar registers; cx.xref[strand] would be a vector load from the argument block and a
+                    // wait for it -- and with it for the next chunk's loads, which are in flight by now)
+                    mm = count_mismatch<NWT, NEWRULE>((strand ? cx.xref[1] : cx.xref[0]) + (loc >> 5), q, off2, nw, st.thr, rc.n_count);
                 }
             } else q = L.q[(hcs >> 16) & 1];
             PH(PH_SCORE);
