@@ -1261,6 +1261,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     if (T >= 1024) { phc.n_bigchunks++; phc.n_bigalive += na; }
                 }
 #endif
+                if (ballot(alive) == 0) continue;  // most chunks: nothing passed the filter, nothing to score or replay
                 if (alive) {
                     uint32_t off2 = (loc & 31) * 2;
                     uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
