@@ -1133,8 +1133,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         const uint32_t e_hcs = L.ent[eif].hcs, e_nfwd = L.ent[eif].nfwd;
                         const SeedEntPl P = L.entp[eif];
                         const bool before = (e_hcs >> 17) != 0;
-                        uint32_t lc = cur.loc_raw - (e_hcs & 0xffffu);
-                        if (((unsigned long long)(lc >> 5) + NWT + 4) >= COLD(nwords)) lc = (uint32_t)guard_idx(cx, G_XREF, lc, 0, r) + BASAL_REF_MARGIN * 32;
+                        const uint32_t lc = cur.loc_raw - (e_hcs & 0xffffu);
                         const uint32_t a_lo = (uint32_t)cur.f, a_hi = (uint32_t)(cur.f >> 32), b_lo = (uint32_t)cur.fb, b_hi = (uint32_t)(cur.fb >> 32);
                         const uint32_t f_lo = (uint32_t)cur.f2, f_hi = (uint32_t)(cur.f2 >> 32);
                         // long window: after the seed = [near | far << 32], before it = [far | near << 32] (bit i = base i of the 64); selects, not branches
@@ -1216,6 +1215,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     alive = (sv.meta >> 9) & 1;
                     gap_ok = (sv.meta >> 10) & 1;
                     loc = sv.loc;
+                    if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
                     hcs = L.ent[ei].hcs;
                 }
                 const uint64_t(*qg)[NWT + 1] = L.q[(hcs >> 16) & 1];
@@ -1247,7 +1247,6 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     const uint32_t e_nfwd = L.ent[ei].nfwd;
                     const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm, e_fc = NEWRULE ? L.ent[ei].fc : 0;
                     loc = cur.loc_raw - (hcs & 0xffffu);
-                    if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
                     strand = cur.jj >= e_nfwd;
                     // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
                     const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e_fr, e_fc, cur.f) & e_fm);
@@ -1263,6 +1262,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
 #endif
                 if (ballot(alive) == 0) continue;  // most chunks: nothing passed the filter, nothing to score or replay
                 if (alive) {
+                    // (the bounds of the reference are checked where it is about to be read, not for every candidate of the stream)
+                    if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
                     uint32_t off2 = (loc & 31) * 2;
                     uint32_t nw = (rc.len + (loc & 31) + 31) / 32;
                     // (strand ? a : b selects between two scalar registers; cx.xref[strand] would be a vector load from the argument block and a
