@@ -935,6 +935,11 @@ int main(int argc, char **argv) {
     if (cli.threads < 1) cli.threads = 1;
 
     double t0 = now();
+    {   // the reference reports an unreadable -d file before anything else happens; so does this, before the GPU is asked for
+        FILE *f = fopen(cli.ref_file.c_str(), "rb");
+        if (!f) die("failed to open reference file (check -d option): " + cli.ref_file);
+        fclose(f);
+    }
     basal_core_t *core = nullptr;
     basal_multi_t *multi = nullptr;
     if (cli.devices.empty()) cli.devices.push_back(cli.device);
