@@ -252,15 +252,20 @@ bool next_record(Reader &r, const basal_params &p, int readset, Rec &o) {
     return true;
 }
 
+// The records of `out` are overwritten in place (a batch vector that comes back from the aligning thread keeps its strings' and vectors'
+// storage: three heap blocks per read otherwise, allocated here and freed there, millions of times per second).
 int load_batch(Reader &r, const basal_params &p, uint32_t read_end, size_t want, int readset, std::vector<Rec> &out, size_t max_bases = ~(size_t)0) {
-    out.clear();
-    size_t bases = 0;
-    for (; out.size() < want && r.index < read_end && bases < max_bases; r.index++) {
-        out.emplace_back();
-        if (!next_record(r, p, readset, out.back())) { out.pop_back(); break; }
-        bases += out.back().seq.size();
+    size_t bases = 0, n = 0;
+    for (; n < want && r.index < read_end && bases < max_bases; r.index++) {
+        if (out.size() <= n) out.emplace_back();
+        Rec &o = out[n];
+        o.qc_failed = 0; o.max_snp = 0; o.has_qual = true;
+        if (!next_record(r, p, readset, o)) break;
+        bases += o.seq.size();
+        n++;
     }
-    return (int)out.size();
+    out.resize(n);
+    return (int)n;
 }
 
 // ReadClass::InitIndex (reads.cpp:13-40): skip the reads before -B
@@ -724,6 +729,41 @@ void run_se_host(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, SeStats &st
 }
 
 // =========================================================================== paired-end: GPU alignment, host pairing
+// a bounded hand-over between a reader thread and the thread that aligns: at most `cap` batches wait
+template <typename T>
+struct BatchQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<T> q;
+    size_t cap = 2;
+    bool closed = false;
+    void push(T &&v) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return q.size() < cap || closed; });
+        if (closed) return;
+        q.push_back(std::move(v));
+        cv.notify_all();
+    }
+    void try_push(T &&v) {  // never waits: what does not fit is dropped
+        std::lock_guard<std::mutex> l(m);
+        if (q.size() < cap && !closed) q.push_back(std::move(v));
+    }
+    bool pop(T &v) {  // false: the producer is done and nothing is left
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        v = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> l(m);
+        closed = true;
+        cv.notify_all();
+    }
+};
+
 void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9], uint64_t &n_pairs, double &t_gpu) {
     basal_params &P = cli.P;
     const int threads = cli.threads;
@@ -745,27 +785,77 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
     const bool device_pairing = al.multi == nullptr && !getenv("BASAL_PE_HOST_PAIRING");
     std::vector<basal_pe_pair> pe_pairs;
     std::vector<basal_pe_rec> pe_recs;
+    double tm[6] = {0, 0, 0, 0, 0, 0};  // waiting for the readers, QC, descriptors, GPU, text, write
+    const double t_begin = now();
+    // Two reader threads, one per mate file, run ahead of the aligning thread by up to two batches. Mate 1's reader decides a batch's size
+    // (a batch's bases must stay below 4 GiB -- 32-bit offsets -- so the base budget may close one early) and tells mate 2's reader.
+    BatchQueue<std::vector<Rec>> qa, qb, qfree;  // qfree: batch vectors the aligning thread is done with, for the readers to fill again
+    BatchQueue<size_t> qn;
+    qn.cap = 4;
+    qfree.cap = 8;
+    auto recycled = [&](std::vector<Rec> &v) {
+        std::lock_guard<std::mutex> l(qfree.m);
+        if (qfree.q.empty()) return;
+        v = std::move(qfree.q.front());
+        qfree.q.pop_front();
+    };
+    std::atomic<bool> stop_readers{false};
+    std::thread ta([&] {
+        while (!stop_readers.load()) {
+            std::vector<Rec> v;
+            recycled(v);
+            const int n1 = load_batch(ra, P, cli.read_end, batch / 2 + 1, 1, v, (size_t)1800 << 20);
+            size_t n = (size_t)n1;
+            qn.push(std::move(n));
+            if (!n1) break;
+            qa.push(std::move(v));
+        }
+        qa.close();
+    });
+    std::thread tb([&] {
+        size_t n1 = 0;
+        while (!stop_readers.load() && qn.pop(n1) && n1) {
+            std::vector<Rec> v;
+            recycled(v);
+            load_batch(rb, P, cli.read_end, n1, 2, v);
+            const bool short_file = v.size() != n1;
+            qb.push(std::move(v));
+            if (short_file) break;
+        }
+        qb.close();
+    });
     for (;;) {
-        // a batch's bases must stay below 4 GiB (32-bit offsets): the base budget closes a batch early
-        int n1 = load_batch(ra, P, cli.read_end, batch / 2 + 1, 1, ra_, (size_t)1800 << 20);
-        int n2 = load_batch(rb, P, cli.read_end, (size_t)n1, 2, rb_);
-        if (!n1 || n1 != n2) break;
-        const size_t np = (size_t)n1;
+        double q0 = now();
+        if (!ra_.empty()) qfree.try_push(std::move(ra_));
+        if (!rb_.empty()) qfree.try_push(std::move(rb_));
+        ra_.clear(); rb_.clear();
+        const bool ga = qa.pop(ra_), gb = ga && qb.pop(rb_);
+        tm[0] += now() - q0;
+        if (!ga || !gb || ra_.empty() || ra_.size() != rb_.size()) break;
+        const size_t np = ra_.size();
+        q0 = now();
         parallel_for(np, threads, [&](size_t b, size_t e, int) {
             for (size_t i = b; i < e; i++) {
                 ra_[i].qc_failed = basal_host_filter_read(&P, ra_[i].seq.data(), ra_[i].qual.data(), &ra_[i].max_snp);
                 rb_[i].qc_failed = basal_host_filter_read(&P, rb_[i].seq.data(), rb_[i].qual.data(), &rb_[i].max_snp);
             }
         });
+        tm[1] += now() - q0;
+        q0 = now();
         descs.assign(2 * np, basal_read{});
         bases.clear();
         stales.clear();
         basal_host_stale_begin_batch(tracker);
+        parallel_for(np, threads, [&](size_t b, size_t e, int) {  // FixPairReadName (pairs.cpp:487-507), pair by pair
+            std::vector<char> na, nb;
+            for (size_t i = b; i < e; i++) {
+                na.assign(ra_[i].name.begin(), ra_[i].name.end()); nb.assign(rb_[i].name.begin(), rb_[i].name.end());
+                na.push_back(0); nb.push_back(0);
+                if (basal_host_fix_pair_names(na.data(), nb.data())) die(basal_last_error());
+                ra_[i].name = na.data(); rb_[i].name = nb.data();
+            }
+        });
         for (size_t i = 0; i < np; i++) {
-            std::vector<char> na(ra_[i].name.begin(), ra_[i].name.end()), nb(rb_[i].name.begin(), rb_[i].name.end());
-            na.push_back(0); nb.push_back(0);
-            if (basal_host_fix_pair_names(na.data(), nb.data())) die(basal_last_error());
-            ra_[i].name = na.data(); rb_[i].name = nb.data();
             const bool both = !ra_[i].qc_failed && !rb_[i].qc_failed;
             for (int m = 0; m < 2; m++) {
                 Rec &rc_ = m ? rb_[i] : ra_[i];
@@ -786,6 +876,7 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
                 }
             }
         }
+        tm[2] += now() - q0;
         if (device_pairing) {
             // one GPU: the pairing rounds run on the device too (basal_pe.hip); what comes back is the list of records to print
             pe_pairs.resize(np);
@@ -806,6 +897,8 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
             }
             for (int k = 0; k < 9; k++) pst[k] += st9[k];
             t_gpu += now() - g0;
+            tm[3] += now() - g0;
+            q0 = now();
             std::vector<std::string> chunks((size_t)std::max(threads, 1));
             parallel_for(np, threads, [&](size_t b, size_t e, int tid) {
                 std::vector<char> line(1 << 16);
@@ -820,7 +913,10 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
                     chunks[(size_t)tid].append(line.data(), (size_t)w);
                 }
             });
+            tm[4] += now() - q0;
+            q0 = now();
             for (auto &c : chunks) out.write(c.data(), c.size());
+            tm[5] += now() - q0;
             n_pairs += np;
             continue;
         }
@@ -857,7 +953,24 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
         for (size_t t = 0; t < chunks.size(); t++) for (int k = 0; k < 9; k++) pst[k] += st[9 * t + k];
         n_pairs += np;
     }
+    // (a mate file that ended early, or an error above: let the readers run out)
+    stop_readers.store(true);
+    qa.close(); qb.close(); qn.close(); qfree.close();
+    ta.join();
+    tb.join();
+    if (cli.verbose >= 1)
+        fprintf(stderr, "\thost side (%.3f s): waiting for the two reader threads %.3f s, QC %.3f s, descriptors %.3f s, GPU batches %.3f s, SAM text %.3f s, writing %.3f s\n",
+                now() - t_begin, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
     basal_host_stale_free(tracker);
+    // The batch vectors hold three heap blocks per read, ten million of them by now; the process is about to exit and the run's clock is
+    // still running, so they are left to the OS instead of being freed one by one (half a second per 4 M reads).
+    if (!getenv("BASAL_CLEAN_EXIT")) {
+        new std::vector<Rec>(std::move(ra_));
+        new std::vector<Rec>(std::move(rb_));
+        new std::deque<std::vector<Rec>>(std::move(qfree.q));
+        new std::deque<std::vector<Rec>>(std::move(qa.q));
+        new std::deque<std::vector<Rec>>(std::move(qb.q));
+    }
     n_pairs = ra.index - cli.read_start + 1;
     ra.close();
     rb.close();
@@ -1012,10 +1125,13 @@ int main(int argc, char **argv) {
         uint64_t n_pairs = 0;
         double t_gpu = 0;
         Aligner al{several ? nullptr : core, multi};
+        const double tp0 = now();
         run_pe(cli, al, R, out, pst, n_pairs, t_gpu);
         out.close();
         if (cli.verbose >= 1) {
-            fprintf(stderr, "[BASAL-MI355X] total read pairs: %llu \ttotal time:  %.2f secs (GPU batches %.3f s)\n", (unsigned long long)n_pairs, now() - t0, t_gpu);
+            const double tp1 = now();
+            fprintf(stderr, "[BASAL-MI355X] total read pairs: %llu \ttotal time:  %.2f secs (align phase %.3f s = %.2f Mpairs/s; GPU batches %.3f s)\n", (unsigned long long)n_pairs,
+                    tp1 - t0, tp1 - tp0, n_pairs / (tp1 - tp0) / 1e6, t_gpu);
             fprintf(stderr, "\taligned pairs: %u, unique pairs: %u, non-unique pairs: %u\n\tunpaired read #1: %u, unique: %u, non-unique: %u\n\tunpaired read #2: %u, unique: %u, non-unique: %u\n",
                     pst[0], pst[1], pst[2], pst[3], pst[4], pst[5], pst[6], pst[7], pst[8]);
         }

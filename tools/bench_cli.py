@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--runs", type=int, default=2)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--pairs", type=int, default=0, help="paired-end: this many read pairs (two FASTQ files, basal -a/-b) instead of --reads single reads")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -47,9 +48,19 @@ def main():
     frm = "ACGT".index(a.rule[0])
     tos = [t for t in a.rule[2:] if t in "ACGT"]
     to = "ACGT".index(tos[0]) if tos else frm
-    with open(fq, "wb") as f:
-        per = 2_000_000
-        for b0 in range(0, a.reads, per):
+    fq2 = os.path.join(a.dir, "r2.fq")
+    if a.pairs:
+        a.reads = 2 * a.pairs
+        with open(fq, "wb") as f1, open(fq2, "wb") as f2:
+            per = 1_000_000
+            for b0 in range(0, a.pairs, per):
+                nb = min(per, a.pairs - b0)
+                m1, m2 = synth_gpu.make_pairs(G, nb, dev, read_len=a.read_len, seed=200 + b0 // per, conv_from=frm, conv_to=to)
+                f1.write(synth_files.fastq_bytes(m1.cpu().numpy().reshape(nb, a.read_len), np.full(nb, a.read_len), None, first=b0))
+                f2.write(synth_files.fastq_bytes(m2.cpu().numpy().reshape(nb, a.read_len), np.full(nb, a.read_len), None, first=b0))
+    with open(fq, "ab" if a.pairs else "wb") as f:
+        per = 2_000_000 if not a.pairs else 1 << 62
+        for b0 in range(0, a.reads if not a.pairs else 0, per):
             nb = min(per, a.reads - b0)
             bases, _, _, _ = synth_gpu.make_reads(G, nb, dev, read_len=a.read_len, seed=100 + b0 // per, conv_from=frm, conv_to=to, p_conv=0.95 if tos else 0.0)
             s = bases.cpu().numpy().reshape(nb, a.read_len)
@@ -59,12 +70,20 @@ def main():
     t_gen = time.time() - t0
     best = None
     for run in range(a.runs):
-        cmd = [os.path.join(ROOT, "basal_amd", "bin", "basal"), "-a", fq, "-d", fa, "-M", a.rule] + a.flags.split() + ["-p", str(a.threads), "-o", out]
+        cmd = [os.path.join(ROOT, "basal_amd", "bin", "basal"), "-a", fq] + (["-b", fq2] if a.pairs else []) + ["-d", fa, "-M", a.rule] + a.flags.split() + ["-p", str(a.threads), "-o", out]
         t1 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
         wall = time.time() - t1
         if r.returncode != 0:
             raise SystemExit("basal failed:\n" + r.stderr)
+        if a.pairs:
+            m = re.search(r"align phase ([0-9.]+) s = ([0-9.]+) Mpairs/s; GPU batches ([0-9.]+) s", r.stderr)
+            d = {"wall_s": round(wall, 2), "align_phase_s": float(m.group(1)), "mpairs_per_s": float(m.group(2)), "mreads_per_s": 2 * float(m.group(2)), "gpu_batches_s": float(m.group(3))}
+            print("[bench_cli] run %d: %s" % (run, d), file=sys.stderr)
+            if best is None or d["mreads_per_s"] > best["mreads_per_s"]:
+                best = d
+            last_log = r.stderr
+            continue
         m = re.search(r"align phase ([0-9.]+) s = ([0-9.]+) Mreads/s; GPU stage sums: H2D ([0-9.]+), read prep ([0-9.]+), align ([0-9.]+), SAM ([0-9.]+), D2H ([0-9.]+)", r.stderr)
         d = {"wall_s": round(wall, 2), "align_phase_s": float(m.group(1)), "mreads_per_s": float(m.group(2)), "gpu_h2d_s": float(m.group(3)), "gpu_prep_s": float(m.group(4)),
              "gpu_align_s": float(m.group(5)), "gpu_sam_s": float(m.group(6)), "gpu_d2h_s": float(m.group(7))}
@@ -77,7 +96,7 @@ def main():
            "log_tail": last_log.strip().splitlines()[-4:]}
     print(json.dumps(res))
     if not a.keep:
-        for f in (fa, fq, out):
+        for f in (fa, fq, fq2, out):
             try:
                 os.remove(f)
             except OSError:
