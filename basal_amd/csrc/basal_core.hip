@@ -849,11 +849,18 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
         gp = (uint32_t)((int)rc.len + (gap_size < 0 ? gap_size : 0) - (int)gp) & 0x1FF;
         l -= (uint32_t)gap_size;
     }
-    if ((int)l < 0) return 0;
-    if (l + rc.len > csize) return 0;
+#ifdef BASAL_PHASE_TIMING  // diagnostic build: what AddHit's calls end in (printed by basal_core_sync_check)
+#define AH_COUNT(k, v) do { if (lane0(lane)) atomicAdd((unsigned long long *)(COLDP(unsigned int, guard) + 31) + PH_N + 4 + 32 + PH_N + (k), (unsigned long long)(v)); } while (0)
+#else
+#define AH_COUNT(k, v) do { } while (0)
+#endif
+    AH_COUNT(0, 1);
+    AH_COUNT(5, st.nlog);
+    if ((int)l < 0) { AH_COUNT(1, 1); return 0; }
+    if (l + rc.len > csize) { AH_COUNT(1, 1); return 0; }
     uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
     const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
-    if (ballot(hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key) & in_regs) return 0;
+    if (ballot(hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key) & in_regs) { AH_COUNT(2, 1); return 0; }
     for (uint32_t base = 64; base < st.nlog; base += 256) {  // long logs: scan the part in memory, four loads in flight per round trip
         bool d = false;
 #pragma unroll
@@ -862,8 +869,10 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
             const basal_hit h = log[idx < st.nlog ? idx : 0];  // (record 0 of the memory log is never written: its slot belongs to the registers)
             d |= idx < st.nlog && hit_key(h.chr >> 1, h.loc, h.gap_size != 0) == key;
         }
-        if (ballot(d)) return 0;
+        AH_COUNT(6, 1);
+        if (ballot(d)) { AH_COUNT(3, 1); return 0; }
     }
+    AH_COUNT(4, 1);
     uint32_t n = st.nlog;
     if (n < COLD(scratch_per_wave)) {
         HitWords u;
@@ -1826,7 +1835,7 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
 #ifdef BASAL_PHASE_TIMING
     {
         static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final", "chunk", "entry", "bytes", "e1", "e2", "e3"};
-        unsigned long long ph[PH_N + 4 + 32 + PH_N], tot = 0;
+        unsigned long long ph[PH_N + 4 + 32 + PH_N + 8], tot = 0;
         HIP_TRY(hipMemcpy(ph, c->d_counter + 32, sizeof ph, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(c->d_counter + 32, 0, sizeof ph));
         fprintf(stderr, "[basal read-time histogram, log2(wave-clocks): count]");
@@ -1840,6 +1849,11 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
             fprintf(stderr, "  (total %llu)\n", ht);
         }
         fprintf(stderr, "[basal counts] chunks %llu alive %llu | in modes with >= 1024 candidates: chunks %llu alive %llu\n", ph[PH_N], ph[PH_N + 1], ph[PH_N + 2], ph[PH_N + 3]);
+        {
+            const unsigned long long *ah = ph + PH_N + 4 + 32 + PH_N;
+            fprintf(stderr, "[basal AddHit] calls %llu: off the contig %llu, known (registers) %llu, known (memory log) %llu, new %llu; mean log length at call %.1f, memory scan rounds %llu\n",
+                    ah[0], ah[1], ah[2], ah[3], ah[4], ah[0] ? (double)ah[5] / ah[0] : 0.0, ah[6]);
+        }
         for (int i = 0; i < PH_N; i++) tot += ph[i];
         fprintf(stderr, "[basal phases]");
         for (int i = 0; i < PH_N; i++) fprintf(stderr, " %s %.1f%%", nm[i], tot ? 100.0 * ph[i] / tot : 0.0);
