@@ -788,7 +788,15 @@ struct HitState {
     uint32_t thr;     // snp_thres
     uint32_t nlog;    // records in the log
     uint32_t d0, d1, d2, d3;  // per lane: the four words of log record `lane`
+    uint32_t bloom;           // per lane: 32 bits of a 2048-bit Bloom filter over the keys of records 64.. (the ones in memory)
 };
+
+// the two filter positions of a key (wave-uniform)
+__device__ __forceinline__ uint32_t bloom_hash(uint64_t key) {
+    uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
+    x *= 0x85EBCA6Bu;
+    return x ^ (x >> 15);
+}
 
 __device__ __forceinline__ uint64_t hit_key(uint32_t contig, uint32_t loc, bool gapped) {
     return ((uint64_t)contig << 33) | ((uint64_t)gapped << 32) | loc;
@@ -861,7 +869,12 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     uint64_t key = hit_key(chr >> 1, l, gap_size != 0);
     const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
     if (ballot(hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0) == key) & in_regs) { AH_COUNT(2, 1); return 0; }
-    for (uint32_t base = 64; base < st.nlog; base += 256) {  // long logs: scan the part in memory, four loads in flight per round trip
+    // Long logs (reads from repeat families: hundreds of hits, nearly all of them new): a key the filter has not seen is in no
+    // memory-resident record, and the scan -- a round trip per 256 records -- is skipped.
+    const uint32_t bh = bloom_hash(key), b1 = bh & 2047u, b2 = (bh >> 11) & 2047u;
+    const bool maybe_known = st.nlog > 64 && ((rdlane(st.bloom, (int)(b1 >> 5)) >> (b1 & 31)) & (rdlane(st.bloom, (int)(b2 >> 5)) >> (b2 & 31)) & 1u);
+    if (maybe_known)
+    for (uint32_t base = 64; base < st.nlog; base += 256) {  // scan the part in memory, four loads in flight per round trip
         bool d = false;
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
@@ -883,6 +896,8 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
         } else {
             if (lane0(lane)) log[n] = u.h;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
+            if ((uint32_t)lane == (b1 >> 5)) st.bloom |= 1u << (b1 & 31);
+            if ((uint32_t)lane == (b2 >> 5)) st.bloom |= 1u << (b2 & 31);
         }
         st.nlog = n + 1;
     }
@@ -1042,6 +1057,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
     st.thr = rc.max_snp;
     st.nlog = 0;
     st.d0 = st.d1 = st.d2 = st.d3 = 0;
+    st.bloom = 0;
     const uint32_t rnd = myrand(rc.index, cx.randseed);
     const uint32_t nent = rfl(2 * cx.I);
     const uint32_t ent_c = (uint32_t)lane >= cx.I ? 1u : 0u, ent_i = (uint32_t)lane >= cx.I ? (uint32_t)lane - cx.I : (uint32_t)lane;  // lane < 2I
