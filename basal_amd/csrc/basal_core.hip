@@ -857,7 +857,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
         gp = (uint32_t)((int)rc.len + (gap_size < 0 ? gap_size : 0) - (int)gp) & 0x1FF;
         l -= (uint32_t)gap_size;
     }
-#ifdef BASAL_PHASE_TIMING  // diagnostic build: what AddHit's calls end in (printed by basal_core_sync_check)
+#ifdef BASAL_COUNT_ADDHIT  // diagnostic build, -DBASAL_PHASE_TIMING -DBASAL_COUNT_ADDHIT: what AddHit's calls end in (printed by basal_core_sync_check; the atomics distort the clocks)
 #define AH_COUNT(k, v) do { if (lane0(lane)) atomicAdd((unsigned long long *)(COLDP(unsigned int, guard) + 31) + PH_N + 4 + 32 + PH_N + (k), (unsigned long long)(v)); } while (0)
 #else
 #define AH_COUNT(k, v) do { } while (0)
@@ -1327,7 +1327,10 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                         acc &= ~bit;
                         ung_pending &= ~bit;
                         uint32_t lmm = rdlane(mm, l);
-                        if (add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane)) { done = true; break; }
+                        PH(PH_REPLAY);
+                        const uint32_t stop = add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane);
+                        PH(PH_E1);  // diagnostic build: AddHit's own time, apart from the replay loop around it
+                        if (stop) { done = true; break; }
                         if (st.thr != thr_before) {
                             acc = ballot(mm <= st.thr) & acc;
                             if (GAP) { gap_pending &= ~(bit - 1); recompute = true; break; }
@@ -1850,7 +1853,7 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
     HIP_TRY(hipStreamSynchronize(c->last_stream));
 #ifdef BASAL_PHASE_TIMING
     {
-        static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final", "chunk", "entry", "bytes", "e1", "e2", "e3"};
+        static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final", "chunk", "entry", "bytes", "addhit", "e2", "e3"};
         unsigned long long ph[PH_N + 4 + 32 + PH_N + 8], tot = 0;
         HIP_TRY(hipMemcpy(ph, c->d_counter + 32, sizeof ph, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(c->d_counter + 32, 0, sizeof ph));
