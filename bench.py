@@ -7,8 +7,8 @@ seed index resident in HBM.  A "step" is ONE call of basal_core_align_batch_devi
 of reads that is already in HBM (descriptors + bases in), plus the copy of that step's 32-byte results
 to page-locked host memory on a second stream, overlapped with the next step's kernel (the timed
 region ends when the last hit record is on the host, SURVEY.md section 8d);
-the default batch is config 2's whole 10 M reads (a launch has a fixed cost of about 1.4 ms -- reads
-from repeats take milliseconds and whichever starts last ends the launch -- so batches of millions
+the default batch is config 2's whole 10 M reads (a launch has a fixed cost of about 0.8 ms -- reads
+from repeats take most of a millisecond and whichever starts last ends the launch -- so batches of millions
 are how the path is meant to be fed; --batch 1000000 reproduces the 1 M-read launches of DESIGN.md's ladder).
 Timing: W warm-up steps, then K steps between barrier + synchronize, max over ranks;
 value = reads aligned by all ranks / that time.  N > 1 (torchrun): every rank holds the whole
@@ -119,7 +119,8 @@ def bench_pairs(args):
     """BASELINE.json config 3: synthetic 150 bp read pairs, -M A:G, on a transcriptome-sized stand-in (154 Mbp, 24 contigs): both mates aligned
     with every SnpAlign mode on the GPU, the pairing rounds on the GPU too (basal_core_align_pairs_batch), the records to print come back.
     A step = one batch of pairs from host buffers to host records (this entry point is host-to-host; the kernel-side time is the two kernels'
-    HIP-event time).  Checked pair by pair against the CPU oracle's pairing on a sample.  One GPU."""
+    HIP-event time).  This leg reports speed only: the path's parity is what tests/test_gpu_parity.py (6 paired-end golden SAMs, the host
+    replay of the same rounds) and tests/test_gpu_cli_scale.py (200 k pairs against the reference binary) check.  One GPU."""
     import torch
     import basal_amd as B
     from basal_amd import core as bc
@@ -475,10 +476,14 @@ def main():
                          "bytes_source": a["source"] + "; kernel_ms = rank 0's launches"})
     # HBM traffic per read from the PMC passes of this same command (profiles/traffic.json, if committed)
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj) and headline:  # a per-launch, per-GPU figure of the headline workload only
+    if os.path.exists(tj):  # a per-launch, per-GPU figure; the committed passes cover the headline workload, configs 4 and 5p and the realistic genome
         t = json.load(open(tj))
-        roof["traffic"] = t["hbm_bytes_per_read"] * args.batch
-        roof["traffic_source"] = t["source"]
+        key = None if headline else ("realistic" if (args.config == "2" and args.genome == "realistic" and args.read_len == 100 and not args.rule and args.gap is None)
+                                     else {"4": "config4", "5p": "config5p"}.get(args.config) if (args.genome == "uniform" and args.read_len == 100 and not args.rule and args.gap is None) else "-")
+        t = t if key is None else t.get("other_workloads", {}).get(key)
+        if t:
+            roof["traffic"] = t["hbm_bytes_per_read"] * args.batch
+            roof["traffic_source"] = t["source"]
     # Host-to-host rate: prepared reads in page-locked host buffers -> H2D -> kernel -> D2H of the hit records, three batches in
     # flight on their own streams (basal_pipe_*, BASAL_PIPE_OUT_RESULTS). Reported next to value, never as value.
     if rank == 0 and world == 1 and not os.environ.get("BASAL_BENCH_NO_H2H"):
