@@ -134,3 +134,43 @@ def test_core_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(B.BasalError):
         B.Core(B.Params("C:T"))
+
+
+def test_transcriptome_generator_layout():
+    """tools/synth_gpu.make_transcriptome (bench.py --config 3's many-contig reference) lays contigs out as RefSeq does: each contig on a
+    word boundary with two pad words, forward strand from the slot's start, reverse complement ending at the slot's end (refbase.cpp:222-244)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+    import synth_gpu
+    p = B.Params("A:G", ["-M", "A:G"])
+    G = synth_gpu.make_transcriptome(p, torch.device("cpu"), n_contigs=300, seed=5)
+    al = [p.c.alphabet[ord(b)] for b in "ACGT"]
+    rv = [p.c.rev_alphabet[ord(b)] for b in "ACGT"]
+    fw = G.words[0].numpy().view(np.uint64)
+    rc = G.words[1].numpy().view(np.uint64)
+    ids = G.ids.numpy()
+    off = G.base_off.numpy()
+
+    def base(words, gpos):
+        return int(words[gpos >> 5] >> np.uint64(62 - 2 * (gpos & 31))) & 3
+    rng = np.random.default_rng(1)
+    for c in [0, 1, 299] + list(rng.integers(0, 300, 20)):
+        L, a = G.sizes[c], int(G.anchors[c])
+        assert int(G.anchors[c + 1]) - a == int(G.rc_offsets[c]) == ((L + 31) // 32 + 2) * 32
+        for i in [0, 1, 31, 32, L // 2, L - 1]:
+            assert base(fw, a + i) == al[ids[off[c] + i]]
+            assert base(rc, a + int(G.rc_offsets[c]) - 1 - i) == rv[ids[off[c] + i]]
+        assert base(fw, a + L) == 0 and base(rc, a + int(G.rc_offsets[c]) - L - 1) == 0
+    blk = G.blocks
+    assert blk.shape == (600, 3) and (blk[0] == [0, 0, G.sizes[0]]).all() and (blk[1] == [1, int(G.rc_offsets[0]) - G.sizes[0], int(G.rc_offsets[0])]).all()
+    m1, m2 = synth_gpu.make_pairs(G, 50, torch.device("cpu"), read_len=150, seed=3, p_conv=0.0, sub_rate=0.0, rev_frac=0.0)
+    flat = "".join("ACGT"[x] for x in ids)
+    comp = str.maketrans("ACGT", "TGCA")
+    for k in range(50):
+        r1 = bytes(m1[k * 150:(k + 1) * 150].numpy()).decode()
+        r2 = bytes(m2[k * 150:(k + 1) * 150].numpy()).decode()
+        s = flat.find(r1)
+        assert s >= 0
+        e = flat.find(r2.translate(comp)[::-1])
+        assert e >= s and e + 150 - s <= 600  # mate 2 = reverse complement of the fragment's end, same contig

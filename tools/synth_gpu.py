@@ -163,6 +163,53 @@ def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=4
     return G
 
 
+def make_transcriptome(params, device, n_contigs=100_000, seed=1, median=1200, sigma=0.8, lo=300, hi=20_000):
+    """A transcriptome-shaped reference for BASELINE.json config 3 ("transcriptome stand-in with <= 131 071
+    contigs"): n_contigs sequences of log-normal length (median 1.2 kb, clipped to lo..hi), uniform ACGT, no N's -- about 0.15 Gbp at
+    100 000 contigs.  Same HBM layout as make_genome (every contig starts on a word boundary and ends with two pad words, the reverse
+    strand in the same slot), built without a Python loop over contigs; G.ids is ONE flat tensor with G.base_off, for make_pairs."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    sizes = np.clip(rng.lognormal(np.log(median), sigma, n_contigs), lo, hi).astype(np.int64)
+    nwords = (sizes + 31) // 32 + 2
+    word_base = np.concatenate([[0], np.cumsum(nwords)])
+    base_off = np.concatenate([[0], np.cumsum(sizes)])
+    total = int(base_off[-1])
+    al, rv = _codes(params)
+    al_t = torch.tensor(al, dtype=torch.uint8, device=device)
+    rv_t = torch.tensor(rv, dtype=torch.uint8, device=device)
+    ids = torch.randint(0, 4, (total,), generator=g, device=device, dtype=torch.uint8)
+    sizes_t = torch.from_numpy(sizes).to(device)
+    cidx = torch.repeat_interleave(torch.arange(n_contigs, device=device), sizes_t)
+    local = torch.arange(total, device=device) - torch.from_numpy(base_off[:-1]).to(device)[cidx]
+    slot0 = torch.from_numpy(word_base[:-1] * 32).to(device)[cidx]
+    slot_len = torch.from_numpy(nwords * 32).to(device)[cidx]
+    tot_bits = int(word_base[-1]) * 32
+    code_f = torch.zeros(tot_bits, dtype=torch.uint8, device=device)
+    code_f[slot0 + local] = al_t[ids.long()]
+    code_r = torch.zeros(tot_bits, dtype=torch.uint8, device=device)
+    code_r[slot0 + slot_len - 1 - local] = rv_t[ids.long()]  # the reverse complement ends where the slot ends
+    del cidx, local, slot0, slot_len
+    pad = torch.zeros(MARGIN, dtype=torch.int64, device=device)
+    G = Genome()
+    G.flat = True
+    G.names = ["t%06d" % i for i in range(n_contigs)]
+    G.sizes = [int(x) for x in sizes]
+    G.ids = ids
+    G.base_off = torch.from_numpy(base_off[:-1]).to(device)
+    G.nmask_runs = None
+    G.words = [torch.cat([pad, _pack(code_f), pad]), torch.cat([pad, _pack(code_r), pad])]
+    del code_f, code_r
+    G.anchors = ((word_base + MARGIN) * 32).astype(np.uint32)
+    G.rc_offsets = (nwords * 32).astype(np.uint32)
+    blk = np.empty((2 * n_contigs, 3), np.uint32)  # one unmasked block per strand (refbase.cpp:103-128), in (id, begin) order
+    blk[0::2, 0] = 2 * np.arange(n_contigs); blk[0::2, 1] = 0; blk[0::2, 2] = sizes
+    blk[1::2, 0] = 2 * np.arange(n_contigs) + 1; blk[1::2, 1] = nwords * 32 - sizes; blk[1::2, 2] = nwords * 32
+    G.blocks = blk
+    return G
+
+
 def make_reads(G, n, device, read_len=100, seed=2, p_conv=0.95, sub_rate=0.01, rev_frac=0.5, conv_from=1, conv_to=3, indel_frac=0.0, indel_max=2,
                del_base=None, del_frac=0.0, del_lo=20, del_hi=80):
     """n reads as ASCII bytes (n*read_len uint8 tensor) plus the truth (contig, 0-based start, strand).
@@ -246,6 +293,18 @@ def make_pairs(G, n, device, read_len=150, frag_min=200, frag_max=600, seed=3, p
     shows its complement."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    if getattr(G, "flat", False):  # make_transcriptome: one flat base array, fragments from the contigs long enough to hold one
+        sizes_t = torch.tensor(G.sizes, dtype=torch.int64)
+        room = (sizes_t - frag_max).clamp(min=0).double()
+        pick = torch.multinomial(room / room.sum(), n, replacement=True, generator=torch.Generator().manual_seed(seed)).to(device)
+        room_p = room.to(device)[pick]
+        start = G.base_off[pick] + (torch.rand(n, generator=g, device=device, dtype=torch.float64) * room_p).long()
+        flen = frag_min + (torch.rand(n, generator=g, device=device) * (frag_max - frag_min + 1)).long().clamp(max=frag_max - frag_min)
+        flen = torch.maximum(flen, torch.full_like(flen, read_len))
+        ar = torch.arange(read_len, device=device)
+        a_ = G.ids[start[:, None] + ar[None, :]]
+        b_ = 3 - G.ids[(start + flen - 1)[:, None] - ar[None, :]]
+        return _finish_pairs(a_, b_, n, g, device, p_conv, sub_rate, rev_frac, conv_from, conv_to)
     segs = []
     for ci, runs in enumerate(G.nmask_runs):
         prev = 0
@@ -270,6 +329,11 @@ def make_pairs(G, n, device, read_len=150, frag_min=200, frag_max=600, seed=3, p
             continue
         a_[m] = G.ids[ci][start[m][:, None] + ar[None, :]]
         b_[m] = 3 - G.ids[ci][(start[m] + flen[m] - 1)[:, None] - ar[None, :]]
+    return _finish_pairs(a_, b_, n, g, device, p_conv, sub_rate, rev_frac, conv_from, conv_to)
+
+
+def _finish_pairs(a_, b_, n, g, device, p_conv, sub_rate, rev_frac, conv_from, conv_to):
+    """a_ = the fragment's first bases, b_ = the reverse complement of its last ones: orientation, conversion, substitutions, ASCII."""
     rev = torch.rand(n, generator=g, device=device) < rev_frac
     r1 = torch.where(rev[:, None], b_, a_)
     r2 = torch.where(rev[:, None], a_, b_)
