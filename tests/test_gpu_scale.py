@@ -228,3 +228,52 @@ def test_gpu_index_build_beyond_2_31_entries():
     p1 = B.Params("C:T", ["-M", "C:T", "-S", "1", "-I", "1"])
     core1, rc1, _ = stage(p1)
     assert rc1 == -1 and b"2^32" in L.basal_last_error()
+
+
+def test_transcriptome_100k_contigs_matches_oracle_on_sample():
+    """BASELINE.json config 3's reference shape (a transcriptome with <= 131 071 contigs): 100 000 contigs, so int2hit searches the
+    anchor table in memory instead of the 64-entry LDS copy.  150-base A:G mates (tools/synth_gpu.make_pairs) aligned single-end with every
+    mode, a sample against the CPU oracle on the same index, and mate 1 of every uniquely aligned pair on the contig mate 2 lies on."""
+    import torch
+    import synth_gpu
+    import oracle_bridge
+    flags = ["-M", "A:G", "-S", "1", "-n", "1"]
+    p = B.Params("A:G", flags)
+    dev = torch.device("cuda", 0)
+    G = synth_gpu.make_transcriptome(p, dev, n_contigs=100_000, seed=2)
+    words = [w.cpu().numpy().view(np.uint64) for w in G.words]
+    sizes = np.array(G.sizes, dtype=np.uint32)
+    core = B.Core(p, 0)
+    L = B.lib()
+    bc._check(L.basal_core_set_reference(core.h, words[0].ctypes.data, words[1].ctypes.data, len(words[0]), G.anchors.ctypes.data, sizes.ctypes.data,
+                                         G.rc_offsets.ctypes.data, len(sizes)), "set_reference")
+    mk = C.c_uint32()
+    blocks = np.ascontiguousarray(G.blocks)
+    bc._check(L.basal_core_build_index(core.h, blocks.ctypes.data, len(blocks), C.byref(mk)), "build_index")
+    npairs, rl = 100_000, 150
+    m1, m2 = synth_gpu.make_pairs(G, npairs, dev, read_len=rl, seed=9)
+    hb = torch.cat([m1, m2]).cpu().numpy()
+    n = 2 * npairs
+    seq = C.create_string_buffer(b"A" * rl, rl + 2)
+    qual = C.create_string_buffer(b"I" * rl, rl + 2)
+    ms = C.c_uint32()
+    assert L.basal_host_filter_read(C.byref(p.c), seq, qual, C.byref(ms)) == 0
+    descs = np.zeros(n, bc.READ_DTYPE)
+    descs["seq_off"] = np.arange(n, dtype=np.uint64) * rl
+    descs["index"] = np.arange(n, dtype=np.uint32)
+    descs["len"], descs["max_snp"], descs["stale_idx"] = rl, ms.value, B.STALE_NONE
+    res = run(core, hb, descs)
+    ns = 12_000
+    ob = oracle_bridge.OracleOnIndex(core, p, flags, G.names, sizes, words)
+    sel = np.linspace(0, n - 1, ns).astype(np.int64)
+    sb = np.concatenate([hb[i * rl:(i + 1) * rl] for i in sel])
+    best, _, _ = ob.align(sb, np.arange(ns, dtype=np.uint32) * rl, descs["len"][sel], descs["index"][sel], descs["max_snp"][sel], 8)
+    bad = oracle_bridge.differing(res[sel], best)
+    assert len(bad) == 0, "reads %s differ from the oracle" % sel[bad][:10]
+    aligned = res["best_level"] != 0xFF
+    assert aligned.mean() > 0.97
+    uniq = aligned & (res["n_hit"].astype(np.uint32) + res["n_chit"] == 1)
+    both = uniq[:npairs] & uniq[npairs:]
+    assert both.mean() > 0.9
+    assert ((res["best"]["chr"][:npairs] >> 1) == (res["best"]["chr"][npairs:] >> 1))[both].all()
+    assert run(core, hb, descs, split=41_111).tobytes() == res.tobytes()
