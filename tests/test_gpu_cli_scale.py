@@ -125,8 +125,8 @@ def test_cli_irregular_text_falls_back_to_host_parsing(tmp_path):
 
 
 def test_cli_pe_200k_pairs_match_reference(tmp_path):
-    """BASELINE.json config 3's shape (150-base pairs, -M A:G) at 200 000 pairs on a transcriptome-like reference of many contigs:
-    the CLI (mates aligned on the GPU, pairing rounds on the host) against the reference binary, byte for byte."""
+    """BASELINE.json config 3's reads (150-base pairs, -M A:G) at 200 000 pairs on a 24-contig reference: the CLI (mates aligned and
+    paired on the GPU) against the reference binary, byte for byte.  (The many-contig reference shapes follow below.)"""
     import torch
     import synth_gpu
     import synth_files
@@ -156,3 +156,66 @@ def test_cli_pe_200k_pairs_match_reference(tmp_path):
     got, want = sam_digest(out), sam_digest(ref)
     assert got[1] == want[1] and got[1] >= 2 * n * 0.9
     assert got[0] == want[0]
+
+
+def _pe_files(tmp, G, n, L, seed):
+    import synth_files
+    import synth_gpu
+    import torch
+    fa, f1, f2 = os.path.join(tmp, "g.fa"), os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+    synth_files.write_fasta(fa, G)
+    b1, b2 = synth_gpu.make_pairs(G, n, torch.device("cuda", 0), read_len=L, seed=seed)
+    s1, s2 = b1.cpu().numpy().reshape(n, L), b2.cpu().numpy().reshape(n, L)
+    d1, l1, q1 = synth_files.dirty(s1, seed + 1, adapter_frac=0.0, lower_frac=0.0)
+    d2, l2, q2 = synth_files.dirty(s2, seed + 2, adapter_frac=0.0, lower_frac=0.0)
+    open(f1, "wb").write(synth_files.fastq_bytes(d1, l1, q1, name_prefix=b"p"))
+    open(f2, "wb").write(synth_files.fastq_bytes(d2, l2, q2, name_prefix=b"p"))
+    return fa, f1, f2
+
+
+def test_cli_pe_transcriptome_5k_contigs_matches_reference(tmp_path):
+    """Config 3's reference SHAPE: thousands of short contigs (more than the 64 the kernel keeps in LDS, three levels of the 64-ary contig
+    search), 60 000 pairs, the CLI with the pairing rounds on the device against the reference binary, byte for byte.  (5 000 contigs, not
+    100 000: the reference clears one std::set per contig and read, align.cpp:437-444.)"""
+    import torch
+    import synth_gpu
+    tmp = str(tmp_path)
+    p = B.Params("A:G", ["-M", "A:G"])
+    G = synth_gpu.make_transcriptome(p, torch.device("cuda", 0), n_contigs=5000, seed=71)
+    n = 60_000
+    fa, f1, f2 = _pe_files(tmp, G, n, 150, 72)
+    del G
+    torch.cuda.empty_cache()
+    flags = ["-M", "A:G", "-S", "1", "-s", "12", "-u", "-x", "700"]
+    out = os.path.join(tmp, "out.sam")
+    r = subprocess.run([BASAL_BIN, "-a", f1, "-b", f2, "-d", fa] + flags + ["-p", "16", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    checker = orc.REF_BIN if os.path.exists(orc.REF_BIN) else orc.CLI
+    c = subprocess.run([checker, "-a", "r1.fq", "-b", "r2.fq", "-d", "g.fa"] + flags + ["-p", "1", "-o", "ref.sam"], capture_output=True, text=True, cwd=tmp)
+    assert c.returncode == 0, c.stderr
+    got, want = sam_digest(out), sam_digest(os.path.join(tmp, "ref.sam"))
+    assert got[1] == want[1] and got[1] >= 2 * n * 0.9
+    assert got[0] == want[0]
+
+
+def test_cli_pe_100k_contigs_device_pairing_equals_host_replay(tmp_path):
+    """The two implementations of PairAlign's rounds -- on the device (basal_pe.hip) and replayed on the host over the mode-tagged logs
+    (basal_pairs.cpp, BASAL_PE_HOST_PAIRING=1) -- on a 100 000-contig transcriptome stand-in, 100 000 pairs, -r 2: the same SAM."""
+    import torch
+    import synth_gpu
+    tmp = str(tmp_path)
+    p = B.Params("A:G", ["-M", "A:G"])
+    G = synth_gpu.make_transcriptome(p, torch.device("cuda", 0), n_contigs=100_000, seed=81)
+    n = 100_000
+    fa, f1, f2 = _pe_files(tmp, G, n, 150, 82)
+    del G
+    torch.cuda.empty_cache()
+    flags = ["-M", "A:G", "-S", "1", "-u", "-x", "700", "-r", "2"]
+    outs = []
+    for env in ({}, {"BASAL_PE_HOST_PAIRING": "1"}):
+        out = os.path.join(tmp, "out%d.sam" % len(outs))
+        r = subprocess.run([BASAL_BIN, "-a", f1, "-b", f2, "-d", fa] + flags + ["-p", "16", "-o", out], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs.append(sam_digest(out))
+    assert outs[0][1] >= 2 * n * 0.9
+    assert outs[0] == outs[1]

@@ -9,6 +9,18 @@ ADAPTER = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
 def write_fasta(path, G, width=60):
     """G: synth_gpu.Genome (base ids per contig on the GPU, N runs)."""
     asc = np.frombuffer(b"ACGT", np.uint8)
+    if getattr(G, "flat", False):  # synth_gpu.make_transcriptome: one flat base array, no N's
+        flat = asc[G.ids.cpu().numpy()]
+        off = G.base_off.cpu().numpy()
+        with open(path, "wb") as f:
+            for name, o, n in zip(G.names, off, G.sizes):
+                s = flat[o:o + n]
+                full = n // width
+                body = np.empty((full, width + 1), np.uint8)
+                body[:, :width] = s[: full * width].reshape(full, width)
+                body[:, width] = ord("\n")
+                f.write(b">" + name.encode() + b"\n" + body.tobytes() + (s[full * width:].tobytes() + b"\n" if n % width else b""))
+        return
     with open(path, "wb") as f:
         for name, ids, runs in zip(G.names, G.ids, G.nmask_runs):
             s = asc[ids.cpu().numpy()]
