@@ -11,11 +11,13 @@
 //      chunk ahead: coalesced location + flank words, a conversion-tolerant flank pre-filter (a lower bound of the
 //      mismatch count), one gather of reference words per surviving lane, XOR/AND + popcount scoring
 //                                                                  (SnpAlign/CountMismatch*, align.cpp:274-316, align.h:118-239)
-//      and the bit-parallel single-gap search                      (GapAlign/MismatchPattern*, align.cpp:348-410)
+//      and the bit-parallel single-gap search                      (GapAlign/MismatchPattern*, align.cpp:348-410);
+//      with -g the stream carries 64 + 32 reference bases per candidate as bit planes, and bounds of the ungapped count and of the
+//      gap search at every shift drop the candidates neither can accept before the reference is touched
 //   5. replays the accepted candidates IN VISITATION ORDER through the sequential hit state
 //      machine (bounds, de-dup, per-level cap, threshold tightening; AddHit align.h:329-347,
 //      int2hit align.cpp:319-346), which is what makes the result bit-identical; the first 64 hits of a read
-//      live in registers
+//      live in registers, a Bloom filter in one more register says which keys the rest of the log cannot hold
 //   6. selects what StringAlign (align.cpp:583-612) would print.
 // All arithmetic is integer/bitwise (no MFMA). DESIGN.md section 4.1 has the measurements: memory gathers, instruction
 // issue and per-read latency all bound it about equally.
