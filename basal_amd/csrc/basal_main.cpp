@@ -11,6 +11,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <atomic>
 #include <chrono>
@@ -140,6 +143,20 @@ struct Rec {
     bool has_qual = true;
 };
 
+// any byte <= ' ' (or >= 0x80) among the n at p: the white space the token reader splits at, conservatively
+inline bool has_space(const char *p, size_t n) {
+    size_t i = 0;
+#if defined(__SSE2__)
+    const __m128i lim = _mm_set1_epi8(33);
+    __m128i acc = _mm_setzero_si128();
+    for (; i + 16 <= n; i += 16) acc = _mm_or_si128(acc, _mm_cmplt_epi8(_mm_loadu_si128((const __m128i *)(p + i)), lim));
+    if (_mm_movemask_epi8(acc)) return true;
+#endif
+    for (; i < n; i++)
+        if ((signed char)p[i] < 33) return true;
+    return false;
+}
+
 const char kNt16[] = "=ACMGRSVTWYHKDBN";
 // what bam_nt16_rev_table[bam_nt16_table[c]] gives (samtools 0.1.18 bam_import.c): the reference reads SAM text through it
 char nt16_roundtrip(char c) {
@@ -221,6 +238,40 @@ bool next_record(Reader &r, const basal_params &p, int readset, Rec &o) {
         }
         if (readset == 1 && !line(skip)) return false;
         return true;
+    }
+    // Fast path for what nearly every FASTQ file is: a record of exactly four lines, wholly inside the window, with nothing the token
+    // reader would treat differently from a line reader (no white space inside or around the sequence and quality lines, no empty name).
+    // Lines are found with memchr and checked 16 bytes at a time; anything else falls through to the token reader below, which is
+    // ReadClass::LoadBatchReads (reads.cpp:42-81) to the letter.
+    if (r.fastq) {
+        if (r.end - r.pos < (1u << 14)) r.ensure(1u << 16);
+        const char *p0 = r.buf.data() + r.pos, *e = r.buf.data() + r.end;
+        if (p0 < e && *p0 == '@') {
+            const char *l1 = (const char *)memchr(p0, '\n', (size_t)(e - p0));
+            const char *l2 = l1 ? (const char *)memchr(l1 + 1, '\n', (size_t)(e - l1 - 1)) : nullptr;
+            const char *l3 = l2 ? (const char *)memchr(l2 + 1, '\n', (size_t)(e - l2 - 1)) : nullptr;
+            const char *l4 = l3 ? (const char *)memchr(l3 + 1, '\n', (size_t)(e - l3 - 1)) : nullptr;
+            if (l4 && l2[1] == '+') {
+                const char *nm = p0 + 1, *ne = nm;
+                while (ne < l1 && !Reader::ws((unsigned char)*ne)) ne++;
+                const size_t sl = (size_t)(l2 - l1 - 1), ql = (size_t)(l4 - l3 - 1);
+                if (ne > nm && sl > 0 && ql > 0 && !has_space(l1 + 1, sl) && !has_space(l3 + 1, ql)) {
+                    o.name.assign(nm, (size_t)(ne - nm));
+                    o.seq.assign(sl + 2, 0);
+                    memcpy(o.seq.data(), l1 + 1, sl);
+                    o.qual.assign(std::max(sl, ql) + 2, 0);
+                    memcpy(o.qual.data(), l3 + 1, ql);
+                    o.index = r.index;
+                    o.readset = (uint32_t)readset;
+                    if (sl > p.max_readlen) {  // reads.cpp:63-65
+                        o.seq[p.max_readlen] = 0;
+                        if (strlen(o.qual.data()) > p.max_readlen) o.qual[p.max_readlen] = 0;
+                    }
+                    r.pos = (size_t)(l4 + 1 - r.buf.data());
+                    return true;
+                }
+            }
+        }
     }
     r.skip_ws();
     if (r.pos >= r.end) return false;
@@ -767,7 +818,9 @@ struct BatchQueue {
 void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9], uint64_t &n_pairs, double &t_gpu) {
     basal_params &P = cli.P;
     const int threads = cli.threads;
-    const size_t batch = cli.batch ? cli.batch : (1u << 20);
+    // 131 072 pairs per batch by default: the three stages (two readers | QC, descriptors, GPU | text, writing) overlap batch by batch, and on
+    // 4 M pairs this size ran 5.6 M pairs/s against 3.2 at 524 288 pairs and 4.0 at 65 536 (the GPU's share grows as launches shrink)
+    const size_t batch = cli.batch ? cli.batch : (1u << 18);
     Reader ra, rb;
     if (!ra.open(cli.qa.c_str())) die("failed to open read file (check -a option): " + cli.qa);
     if (!rb.open(cli.qb.c_str())) die("failed to open read file #2 (check -b option): " + cli.qb);
@@ -800,29 +853,66 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
         qfree.q.pop_front();
     };
     std::atomic<bool> stop_readers{false};
+    // (reads are cut to max_readlen when they are parsed, so below ~3.9 M pairs per batch the base budget cannot close a batch early and
+    // mate 2's reader need not wait to be told the size)
+    const bool same_size = (batch / 2 + 1) * (size_t)(P.max_readlen + 2) < ((size_t)1800 << 20);
     std::thread ta([&] {
         while (!stop_readers.load()) {
             std::vector<Rec> v;
             recycled(v);
             const int n1 = load_batch(ra, P, cli.read_end, batch / 2 + 1, 1, v, (size_t)1800 << 20);
             size_t n = (size_t)n1;
-            qn.push(std::move(n));
+            if (!same_size) qn.push(std::move(n));
             if (!n1) break;
             qa.push(std::move(v));
         }
         qa.close();
     });
     std::thread tb([&] {
-        size_t n1 = 0;
-        while (!stop_readers.load() && qn.pop(n1) && n1) {
+        size_t n1 = batch / 2 + 1;
+        while (!stop_readers.load() && (same_size || (qn.pop(n1) && n1))) {
             std::vector<Rec> v;
             recycled(v);
             load_batch(rb, P, cli.read_end, n1, 2, v);
+            if (same_size && v.empty()) break;
             const bool short_file = v.size() != n1;
             qb.push(std::move(v));
             if (short_file) break;
         }
         qb.close();
+    });
+    // Third stage (device pairing): the records of a batch are turned into text and written while the next batch is prepared and aligned.
+    struct PeOut { std::vector<Rec> a, b; std::vector<basal_pe_pair> pairs; std::vector<basal_pe_rec> recs; };
+    BatchQueue<PeOut> qfmt, qpool;  // qpool: pair/record vectors to use again
+    std::thread tf([&] {
+        PeOut po;
+        while (qfmt.pop(po)) {
+            const size_t np = po.a.size();
+            double f0 = now();
+            std::vector<std::string> chunks((size_t)std::max(threads, 1));
+            parallel_for(np, threads, [&](size_t b, size_t e, int tid) {
+                std::vector<char> line(1 << 16);
+                for (size_t i = b; i < e; i++) {
+                    const Rec &x = po.a[i], &y = po.b[i];
+                    basal_mate ma{x.name.c_str(), x.seq.data(), x.qual.data(), 1, x.index, x.max_snp, x.qc_failed, nullptr};
+                    basal_mate mb{y.name.c_str(), y.seq.data(), y.qual.data(), 2, y.index, y.max_snp, y.qc_failed, nullptr};
+                    if (po.pairs[i].status) die("align_pairs_batch: a pair's records did not fit");
+                    size_t need = 8192 + (size_t)(po.pairs[i].n + 2) * (2048 + 2 * (x.seq.size() + y.seq.size()));
+                    if (line.size() < need) line.resize(need);
+                    int64_t w = basal_host_format_pe_records(&P, R, &ma, &mb, po.recs.data() + po.pairs[i].first, po.pairs[i].n, line.data(), line.size());
+                    if (w < 0) die(std::string("format_pe_records: ") + basal_last_error());
+                    chunks[(size_t)tid].append(line.data(), (size_t)w);
+                }
+            });
+            tm[4] += now() - f0;
+            f0 = now();
+            for (auto &c : chunks) out.write(c.data(), c.size());
+            tm[5] += now() - f0;
+            qfree.try_push(std::move(po.a));
+            qfree.try_push(std::move(po.b));
+            po.a.clear(); po.b.clear();
+            qpool.try_push(std::move(po));
+        }
     });
     for (;;) {
         double q0 = now();
@@ -898,25 +988,19 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
             for (int k = 0; k < 9; k++) pst[k] += st9[k];
             t_gpu += now() - g0;
             tm[3] += now() - g0;
-            q0 = now();
-            std::vector<std::string> chunks((size_t)std::max(threads, 1));
-            parallel_for(np, threads, [&](size_t b, size_t e, int tid) {
-                std::vector<char> line(1 << 16);
-                for (size_t i = b; i < e; i++) {
-                    basal_mate ma{ra_[i].name.c_str(), ra_[i].seq.data(), ra_[i].qual.data(), 1, ra_[i].index, ra_[i].max_snp, ra_[i].qc_failed, nullptr};
-                    basal_mate mb{rb_[i].name.c_str(), rb_[i].seq.data(), rb_[i].qual.data(), 2, rb_[i].index, rb_[i].max_snp, rb_[i].qc_failed, nullptr};
-                    if (pe_pairs[i].status) die("align_pairs_batch: a pair's records did not fit");
-                    size_t need = 8192 + (size_t)(pe_pairs[i].n + 2) * (2048 + 2 * (ra_[i].seq.size() + rb_[i].seq.size()));
-                    if (line.size() < need) line.resize(need);
-                    int64_t w = basal_host_format_pe_records(&P, R, &ma, &mb, pe_recs.data() + pe_pairs[i].first, pe_pairs[i].n, line.data(), line.size());
-                    if (w < 0) die(std::string("format_pe_records: ") + basal_last_error());
-                    chunks[(size_t)tid].append(line.data(), (size_t)w);
+            {   // hand the batch to the text stage; its vectors come back through qfree / qpool
+                PeOut po;
+                po.a = std::move(ra_); po.b = std::move(rb_); po.pairs = std::move(pe_pairs); po.recs = std::move(pe_recs);
+                ra_.clear(); rb_.clear();
+                qfmt.push(std::move(po));
+                PeOut spare;
+                {
+                    std::lock_guard<std::mutex> l(qpool.m);
+                    if (!qpool.q.empty()) { spare = std::move(qpool.q.front()); qpool.q.pop_front(); }
                 }
-            });
-            tm[4] += now() - q0;
-            q0 = now();
-            for (auto &c : chunks) out.write(c.data(), c.size());
-            tm[5] += now() - q0;
+                pe_pairs = std::move(spare.pairs);
+                pe_recs = std::move(spare.recs);
+            }
             n_pairs += np;
             continue;
         }
@@ -954,6 +1038,8 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
         n_pairs += np;
     }
     // (a mate file that ended early, or an error above: let the readers run out)
+    qfmt.close();  // (pop hands out what is still queued before it reports the end)
+    tf.join();
     stop_readers.store(true);
     qa.close(); qb.close(); qn.close(); qfree.close();
     ta.join();
