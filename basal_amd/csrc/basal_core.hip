@@ -1270,6 +1270,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 hcs = L.ent[ei].hcs;
                 q = L.q[(hcs >> 16) & 1];
                 bool alive = false;
+                uint32_t lb_first = 0;
                 if (active) {
                     const uint32_t e_nfwd = L.ent[ei].nfwd;
                     const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm, e_fc = NEWRULE ? L.ent[ei].fc : 0;
@@ -1278,6 +1279,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                     // flank pre-filter on the coalesced stream: a lower bound of the mismatch count
                     const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(e_fr, e_fc, cur.f) & e_fm);
                     alive = lb <= st.thr;
+                    lb_first = lb;
                     PH(PH_FILTER);
                 }
 #ifdef BASAL_PHASE_TIMING
@@ -1288,6 +1290,23 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 }
 #endif
                 if (ballot(alive) == 0) continue;  // most chunks: nothing passed the filter, nothing to score or replay
+                // A mode with a long stream (a read from a repeat family: thousands of near-copies, half of which pass one 32-base window):
+                // what passed is tested against the window on the seed's OTHER side too before it may touch the reference -- 8 coalesced
+                // bytes per candidate against a 128-byte reference line per survivor. Fetched here, for the lanes still alive, rather
+                // than with the stream (two more registers live across the loop cost the common read 4 %). It is one more dependent round
+                // trip per chunk, which pays in throughput where long streams are the rule -- an index whose over-represented-k-mer
+                // cut-off is high (107 091 on the repeat-realistic genome: +30 %) -- and costs latency where they are the exception (11 507 on
+                // the uniform stand-in, whose one planted family then ends a 50 000-read launch 10-30 % later): hence the second condition.
+                if (__builtin_expect(T >= 1024u && cx.max_kmer_num >= 32768u, 0)) {
+                    if (alive) {
+                        const uint32_t h = hcs & 0xffffu;
+                        const uint64_t fo = cx.flank_a[(unsigned long long)(L.ent[ei].off + cur.jj) + ((hcs >> 17) ? 0ULL : flank_b_off)];
+                        uint64_t wr, wm, wc;
+                        plane_window3<NWT, NEWRULE>(q, (hcs >> 17) ? (int)(h + cx.K) : (int)h - 32, wr, wm, wc);
+                        alive = lb_first + XM64(cmp_word<NEWRULE>(wr, wc, fo) & wm) <= st.thr;
+                    }
+                    if (ballot(alive) == 0) continue;
+                }
                 if (alive) {
                     // (the bounds of the reference are checked where it is about to be read, not for every candidate of the stream)
                     if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
