@@ -59,6 +59,7 @@ struct DevCtx {
     const uint32_t *kmer_off, *kmer_nfwd, *locs;
     const uint64_t *flank_a, *flank_b;  // 32 reference bases after / before each index entry's seed
     uint32_t max_kmer_num;
+    uint32_t win2_min_T;  // a mode's stream of at least this many candidates tests filter survivors against the second window (process_read); ~0u = never
     uint32_t K, I, max_num_hits, chains, randseed, gap, gap_edge, n_mis, stream_mode, report_repeat_hits;
     const uint8_t *tables;  // alphabet, rev_alphabet, reg_alphabet, alphabet_mread, rev_alphabet_mread
     const uint8_t *bases;
@@ -1297,7 +1298,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 // trip per chunk, which pays in throughput where long streams are the rule -- an index whose over-represented-k-mer
                 // cut-off is high (107 091 on the repeat-realistic genome: +30 %) -- and costs latency where they are the exception (11 507 on
                 // the uniform stand-in, whose one planted family then ends a 50 000-read launch 10-30 % later): hence the second condition.
-                if (__builtin_expect(T >= 1024u && cx.max_kmer_num >= 32768u, 0)) {
+                // (the launch folds both into cx.win2_min_T: 1 024, or never)
+                if (__builtin_expect(T >= cx.win2_min_T, 0)) {
                     if (alive) {
                         const uint32_t h = hcs & 0xffffu;
                         const uint64_t fo = cx.flank_a[(unsigned long long)(L.ent[ei].off + cur.jj) + ((hcs >> 17) ? 0ULL : flank_b_off)];
@@ -1800,6 +1802,14 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     cx.xref[0] = c->d_xref[0]; cx.xref[1] = c->d_xref[1];
     cx.ref_anchor = c->d_anchor; cx.contig_size = c->d_size; cx.rc_offset = c->d_rcoff; cx.ncontig = c->ncontig;
     cx.kmer_off = c->d_koff; cx.kmer_nfwd = c->d_knfwd; cx.locs = c->d_locs; cx.max_kmer_num = c->max_kmer_num;
+    {   // BASAL_SECOND_WINDOW="<min stream length>:<min cut-off>" overrides the rule (tests run every fixture through the second window with "1:0")
+        uint32_t min_T = 1024, min_cut = 32768;
+        if (const char *e = getenv("BASAL_SECOND_WINDOW")) {
+            unsigned a = 0, b = 0;
+            if (sscanf(e, "%u:%u", &a, &b) == 2) { min_T = a; min_cut = b; }
+        }
+        cx.win2_min_T = c->max_kmer_num >= min_cut ? min_T : 0xFFFFFFFFu;
+    }
     cx.flank_a = c->d_flank_a; cx.flank_b = c->d_flank_b;
     cx.K = c->p.seed_size; cx.I = c->p.index_interval; cx.max_num_hits = c->p.max_num_hits; cx.chains = c->p.chains;
     cx.randseed = c->p.randseed; cx.gap = c->p.gap; cx.gap_edge = c->p.gap_edge; cx.n_mis = c->p.n_mis;

@@ -87,6 +87,22 @@ def test_gap_stream_bounds_never_drop_an_accepted_candidate():
     assert m and int(m.group(1)) >= len(gap), r.stdout[-500:]
 
 
+def test_second_window_on_every_fixture():
+    """In long streams of repeat-rich indexes the non-GAP kernels test filter survivors against the window on the seed's other side before they
+    touch the reference.  No fixture is large enough to get there by itself, so BASAL_SECOND_WINDOW=1:0 sends EVERY chunk's
+    survivors through it: all hit logs must still be the oracle's, all SAMs the golden ones."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BASAL_SECOND_WINDOW="1:0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_hit_logs_match_oracle or test_sam_matches_golden_through_abi"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 2 * len(H.SE), r.stdout[-500:]
+
+
 @pytest.mark.parametrize("name", H.SE)
 def test_sam_matches_golden_through_abi(name):
     flags = H.MANIFEST[name]["flags"]
