@@ -1302,7 +1302,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 if (__builtin_expect(T >= cx.win2_min_T, 0)) {
                     if (alive) {
                         const uint32_t h = hcs & 0xffffu;
-                        const uint64_t fo = cx.flank_a[(unsigned long long)(L.ent[ei].off + cur.jj) + ((hcs >> 17) ? 0ULL : flank_b_off)];
+                        const uint64_t fo = cx.flank_a[(unsigned long long)guard_u32(cx, G_LOCS, L.ent[ei].off + cur.jj, nlocs_u, r) + ((hcs >> 17) ? 0ULL : flank_b_off)];
                         uint64_t wr, wm, wc;
                         plane_window3<NWT, NEWRULE>(q, (hcs >> 17) ? (int)(h + cx.K) : (int)h - 32, wr, wm, wc);
                         alive = lb_first + XM64(cmp_word<NEWRULE>(wr, wc, fo) & wm) <= st.thr;
