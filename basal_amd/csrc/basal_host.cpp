@@ -10,9 +10,14 @@
 // layout the GPU gathers from; the CPU build is a two-pass counting sort split over threads by
 // k-mer range, which reproduces the reference's per-k-mer order (forward ascending, then RC
 // ascending) without its 16-byte header table.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
@@ -162,6 +167,10 @@ static bool read_all(const char *path, std::string &out) {
     gzFile f = gzopen(path, "rb");
     if (!f) return false;
     gzbuffer(f, 1 << 20);
+    {   // a plain file's size is known: one allocation instead of a 3 GB string growing by doubling
+        struct stat st;
+        if (stat(path, &st) == 0 && st.st_size > 0) out.reserve((size_t)st.st_size + 1);
+    }
     std::vector<char> buf(1 << 22);
     int got;
     while ((got = gzread(f, buf.data(), (unsigned)buf.size())) > 0) out.append(buf.data(), (size_t)got);
@@ -171,11 +180,89 @@ static bool read_all(const char *path, std::string &out) {
 
 static inline bool ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
 
+// the sequence tokens of one record, from `pos` to the next token that starts with '>' (or the end): appended to sq; returns where it stopped
+static size_t append_sequence(const char *buf, size_t pos, size_t len, std::string &sq) {
+    for (;;) {
+        while (pos < len && ws((unsigned char)buf[pos])) pos++;
+        if (pos >= len || buf[pos] == '>') break;
+        // a whole line at once when it is one token (what FASTA lines are): memchr for its end, then a check for white space inside
+        const char *nl = (const char *)memchr(buf + pos, '\n', len - pos);
+        const size_t le = nl ? (size_t)(nl - buf) : len;
+        bool plain = true;
+        for (size_t i = pos; i < le; i++)
+            if ((unsigned char)buf[i] <= ' ') { plain = false; break; }
+        if (plain) {
+            sq.append(buf + pos, le - pos);
+            pos = le;
+            continue;
+        }
+        size_t b = pos;
+        while (pos < len && !ws((unsigned char)buf[pos])) pos++;
+        sq.append(buf + b, pos - b);
+    }
+    return pos;
+}
+
+// A FASTA file laid out the usual way -- it starts with '>', every record's '>' is the first byte of a line, any other '>' sits inside a
+// header line, a name follows each '>' at once -- splits into records at those line starts, and the records' sequences are then gathered
+// in parallel (RefSeq::LoadNextSeq's token reader would read them the same way). Returns false for anything else: the caller then
+// walks the file token by token.
+static bool split_records(const char *buf, size_t len, std::vector<size_t> &starts) {
+    if (len == 0 || buf[0] != '>') return false;
+    size_t hdr_end = 0;  // end of the current header line
+    for (size_t p = 0; p < len;) {
+        const char *g = (const char *)memchr(buf + p, '>', len - p);
+        if (!g) break;
+        const size_t q = (size_t)(g - buf);
+        if (q == 0 || buf[q - 1] == '\n') {
+            if (q + 1 >= len || ws((unsigned char)buf[q + 1])) return false;
+            starts.push_back(q);
+            const char *nl = (const char *)memchr(buf + q, '\n', len - q);
+            hdr_end = nl ? (size_t)(nl - buf) : len;
+            p = hdr_end;
+        } else if (q < hdr_end) p = q + 1;  // inside a header line (unreachable: the scan resumes behind it; kept for clarity)
+        else return false;                  // a '>' in the middle of a sequence line: leave it to the token reader
+    }
+    return !starts.empty();
+}
+
 extern "C" int basal_host_ref_load_mem(const basal_params *p, const char *buf, size_t len, basal_ref_t **out) {
     if (!p || !buf || !out) { set_error("ref_load: null argument"); return BASAL_EINVAL; }
     basal_ref *r = new basal_ref();
     std::vector<std::string> seqs;
     size_t pos = 0;
+    std::vector<size_t> starts;
+    if (len >= (1u << 20) && split_records(buf, len, starts)) {
+        const size_t nr = starts.size();
+        std::vector<std::string> names(nr);
+        seqs.resize(nr);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= nr) break;
+                const size_t end = k + 1 < nr ? starts[k + 1] : len;
+                size_t q = starts[k] + 1, b = q;
+                while (q < end && !ws((unsigned char)buf[q])) q++;
+                names[k].assign(buf + b, q - b);
+                while (q < end && buf[q] != '\n') q++;
+                seqs[k].reserve(end - q);
+                append_sequence(buf, q, end, seqs[k]);
+            }
+        };
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt < 1 ? 1 : nt > 16 ? 16 : nt;
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt && k < nr; k++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        size_t keep = 0;
+        while (keep < nr && !seqs[keep].empty()) keep++;  // a zero-length record ends loading (refbase.cpp:192)
+        seqs.resize(keep);
+        names.resize(keep);
+        r->name = std::move(names);
+        pos = len;
+    }
     // iostream-token semantics of RefSeq::LoadNextSeq (refbase.cpp:17-38)
     for (;;) {
         while (pos < len && ws((unsigned char)buf[pos])) pos++;
@@ -188,13 +275,7 @@ extern "C" int basal_host_ref_load_mem(const basal_params *p, const char *buf, s
         while (pos < len && buf[pos] != '\n') pos++;
         if (pos < len) pos++;
         std::string sq;
-        for (;;) {
-            while (pos < len && ws((unsigned char)buf[pos])) pos++;
-            if (pos >= len || buf[pos] == '>') break;
-            b = pos;
-            while (pos < len && !ws((unsigned char)buf[pos])) pos++;
-            sq.append(buf + b, pos - b);
-        }
+        pos = append_sequence(buf, pos, len, sq);
         if (sq.empty()) break;  // a zero-length record ends loading (refbase.cpp:192)
         r->name.push_back(nm);
         seqs.push_back(std::move(sq));
@@ -219,34 +300,64 @@ extern "C" int basal_host_ref_load_mem(const basal_params *p, const char *buf, s
     const uint64_t nw = s + 2 * BASAL_REF_MARGIN;
     r->words[0].assign(nw, 0);
     r->words[1].assign(nw, 0);
-    for (size_t ci = 0; ci < nc; ci++) {
-        const std::string &sq = seqs[ci];
-        const uint32_t L = r->size[ci], n = r->nword[ci], tot = n * 32;
-        uint64_t *fw = r->words[0].data() + r->word_base[ci], *rc = r->words[1].data() + r->word_base[ci];
-        // forward strand, MSB first; the tail is 'N' (code alphabet['N'] = 0)
-        for (uint32_t i = 0; i < L; i++) fw[i >> 5] |= (uint64_t)p->alphabet[(unsigned char)sq[i]] << (62 - 2 * (i & 31));
-        // reverse complement of the padded sequence: base j of the RC array is the complement of base tot-1-j
-        for (uint32_t i = 0; i < L; i++) {
-            uint32_t j = tot - 1 - i;
-            rc[j >> 5] |= (uint64_t)p->rev_alphabet[(unsigned char)sq[i]] << (62 - 2 * (j & 31));
-        }
-        // blocks: maximal runs starting at an ACGT and ending before the next N/X, kept if >= 16 long
-        // (UnmaskRegion, refbase.cpp:103-128; its "merge" branch never fires)
-        uint32_t e = 0;
-        while (e < L) {
-            uint32_t b = e;
-            while (b < L && !p->reg_alphabet[(unsigned char)sq[b]]) b++;
-            if (b >= L) break;
-            e = b;
-            while (e < L) {
-                char ch = sq[e];
-                if (ch == 'N' || ch == 'X' || ch == 'n' || ch == 'x') break;
-                e++;
+    // Packing is per (contig, slice of 2^20 bases): a slice starts on a word boundary of the forward strand, and -- the slot being a
+    // whole number of words -- of the reverse strand too, so slices write disjoint words. The unmasked blocks are found per contig.
+    {
+        struct Task { uint32_t ci, b, e; };
+        std::vector<Task> tasks;
+        for (size_t ci = 0; ci < nc; ci++)
+            for (uint32_t b = 0; b < r->size[ci]; b += 1u << 20) tasks.push_back({(uint32_t)ci, b, std::min<uint32_t>(r->size[ci], b + (1u << 20))});
+        std::vector<std::vector<uint32_t>> cblocks(nc);
+        std::atomic<size_t> next_task{0}, next_contig{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next_task.fetch_add(1);
+                if (k >= tasks.size()) break;
+                const Task t = tasks[k];
+                const std::string &sq = seqs[t.ci];
+                const uint32_t tot = r->nword[t.ci] * 32;
+                uint64_t *fw = r->words[0].data() + r->word_base[t.ci], *rc = r->words[1].data() + r->word_base[t.ci];
+                // forward strand, MSB first; the tail is 'N' (code alphabet['N'] = 0)
+                for (uint32_t i = t.b; i < t.e; i++) fw[i >> 5] |= (uint64_t)p->alphabet[(unsigned char)sq[i]] << (62 - 2 * (i & 31));
+                // reverse complement of the padded sequence: base j of the RC array is the complement of base tot-1-j
+                for (uint32_t i = t.b; i < t.e; i++) {
+                    const uint32_t j = tot - 1 - i;
+                    rc[j >> 5] |= (uint64_t)p->rev_alphabet[(unsigned char)sq[i]] << (62 - 2 * (j & 31));
+                }
             }
-            if (e - b < 16) continue;
-            r->blocks.insert(r->blocks.end(), {(uint32_t)(2 * ci), b, e});
-            r->blocks.insert(r->blocks.end(), {(uint32_t)(2 * ci + 1), tot - e, tot - b});
-        }
+            for (;;) {
+                const size_t ci = next_contig.fetch_add(1);
+                if (ci >= nc) break;
+                const std::string &sq = seqs[ci];
+                const uint32_t L = r->size[ci], tot = r->nword[ci] * 32;
+                std::vector<uint32_t> &bl = cblocks[ci];
+                // blocks: maximal runs starting at an ACGT and ending before the next N/X, kept if >= 16 long
+                // (UnmaskRegion, refbase.cpp:103-128; its "merge" branch never fires)
+                uint32_t e = 0;
+                while (e < L) {
+                    uint32_t b = e;
+                    while (b < L && !p->reg_alphabet[(unsigned char)sq[b]]) b++;
+                    if (b >= L) break;
+                    e = b;
+                    while (e < L) {
+                        char ch = sq[e];
+                        if (ch == 'N' || ch == 'X' || ch == 'n' || ch == 'x') break;
+                        e++;
+                    }
+                    if (e - b < 16) continue;
+                    bl.insert(bl.end(), {(uint32_t)(2 * ci), b, e});
+                    bl.insert(bl.end(), {(uint32_t)(2 * ci + 1), tot - e, tot - b});
+                }
+            }
+        };
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt < 1 ? 1 : nt > 16 ? 16 : nt;
+        if (tasks.size() < 4) nt = 1;
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; k++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (size_t ci = 0; ci < nc; ci++) r->blocks.insert(r->blocks.end(), cblocks[ci].begin(), cblocks[ci].end());
     }
     // sort by (id, begin) (refbase.cpp:184,219)
     {
@@ -267,6 +378,24 @@ extern "C" int basal_host_ref_load_mem(const basal_params *p, const char *buf, s
 }
 
 extern "C" int basal_host_ref_load(const basal_params *p, const char *path, basal_ref_t **out) {
+    if (path) {  // a plain (not gzip) file is parsed where the page cache has it, without a copy
+        int fd = open(path, O_RDONLY);
+        if (fd >= 0) {
+            struct stat st;
+            unsigned char magic[2] = {0, 0};
+            if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= (1 << 20) && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    const int rc = basal_host_ref_load_mem(p, (const char *)m, (size_t)st.st_size, out);
+                    munmap(m, (size_t)st.st_size);
+                    close(fd);
+                    return rc;
+                }
+            }
+            close(fd);
+        }
+    }
     std::string buf;
     if (!path || !read_all(path, buf)) {
         set_error(std::string("failed to open reference file (check -d option): ") + (path ? path : "(null)"));
