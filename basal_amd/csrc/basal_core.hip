@@ -959,7 +959,7 @@ __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L
         const uint32_t e_off = L.ent[ei].off, e_m = L.ent[ei].m, e_jj0 = L.ent[ei].jj0, e_pre = L.ent[ei].pre, e_hcs = L.ent[ei].hcs;
         uint32_t jj = e_jj0 + (t - e_pre);
         if (jj >= e_m) jj -= e_m;
-        const uint32_t x = guard_u32(cx, G_LOCS, e_off + jj, nlocs_u, r);  // kmer_off is 32-bit, so list positions are too
+        const uint32_t x = e_off + jj;  // inside locs[] (the mode's set-up checked off + m per seed); kmer_off is 32-bit, so list positions are too
         c.loc_raw = cx.locs[x];
         if (BOTH) { c.f = cx.flank_a[x]; c.fb = cx.flank_a[flank_b_off + x]; c.f2 = cx.flank_a[(2ULL + (e_hcs >> 17)) * flank_b_off + x]; }
         else c.f = cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)];
@@ -1103,6 +1103,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
             const uint32_t side = (uint32_t)(n_before > n_after);
             uint64_t wr = 0, wm = 0, wc = 0;
             if (!GAP) plane_window3<NWT, NEWRULE>(L.q[e_chain], side ? (int)e_h - 32 : (int)(e_h + cx.K), wr, wm, wc);
+            // the list must lie inside locs[]: checked here, once per seed, so that the stream's chunks need not check every position
+            if ((unsigned long long)e_off + e_m > COLD(nlocs)) e_off = guard_u32(cx, G_LOCS, e_off + e_m, 0, r);
             SeedEntT<GAP> e;
             e.off = e_off; e.m = e_m; e.nfwd = e_nfwd; e.jj0 = e_jj0; e.pre = inc - e_m; e.hcs = e_h | (e_chain << 16) | (side << 17);
             if constexpr (!GAP) { e.fr = wr; e.fm = wm; e.fc = wc; }
