@@ -174,3 +174,46 @@ def test_transcriptome_generator_layout():
         assert s >= 0
         e = flat.find(r2.translate(comp)[::-1])
         assert e >= s and e + 150 - s <= 600  # mate 2 = reverse complement of the fragment's end, same contig
+
+
+@pytest.mark.parametrize("layout", ["regular", "crlf_and_wrapped", "gt_in_sequence_line"])
+def test_large_fasta_loader_matches_oracle(layout, tmp_path):
+    """FASTA files of a megabyte and more take basal_host_ref_load's parallel path (records found at their line starts, sequences gathered
+    and packed by several threads) when they are laid out the usual way, and the token reader otherwise: either way the packed strands,
+    anchors and unmasked blocks are the oracle's (which reads the file the way RefSeq::LoadNextSeq does)."""
+    rng = np.random.default_rng(17)
+    parts = []
+    for c in range(7):
+        n = int(rng.integers(150_000, 600_000))
+        s = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+        for _ in range(5):  # N runs, lower case, other IUPAC letters
+            a = int(rng.integers(0, n - 3000))
+            s[a:a + int(rng.integers(1, 2500))] = ord("N")
+        lo = int(rng.integers(0, n - 5000))
+        s[lo:lo + 4000] |= 0x20
+        s[rng.integers(0, n, 20)] = ord("R")
+        w = [60, 70, 61, 80, 50, 100, 64][c]
+        body = b"\n".join(s[i:i + w].tobytes() for i in range(0, n, w))
+        parts.append(b">ctg%d some description > with an arrow\n" % c + body + b"\n")
+    text = b"".join(parts)
+    if layout == "crlf_and_wrapped":
+        text = text.replace(b"\n", b"\r\n", 3000)            # a stretch of CRLF lines: white space inside what a line reader sees
+    elif layout == "gt_in_sequence_line":
+        k = text.index(b"\n", 2_000_000)
+        text = text[:k] + b" >x\nACGTACGTACGTACGTACGTACGT" + text[k:]  # a token that starts a record in the middle of a line
+    fa = str(tmp_path / "big.fa")
+    open(fa, "wb").write(text)
+    flags = ["-M", "C:T", "-s", "12"]
+    p = B.Params("C:T", flags)
+    ref = B.Reference(p, fasta_path=fa)
+    o = orc.Oracle(flags, fa)
+    a = o.arrays()
+    assert ref.names() == a["names"]
+    assert np.array_equal(ref.sizes(), a["size"])
+    assert np.array_equal(ref.anchors(), a["anchor"])
+    assert np.array_equal(ref.words(0), a["xref0"])
+    assert np.array_equal(ref.words(1), a["xref1"])
+    ref.build_index(4)
+    off, nfwd, locs, mk = ref.index()
+    assert np.array_equal(locs, a["locs"]) and np.array_equal(nfwd, a["n_fwd"]) and mk == a["max_kmer_num"]
+    o.close()
