@@ -632,8 +632,10 @@ extern "C" int basal_host_stale_visit(basal_stale_tracker_t *t, const char *seq,
                 out->overlay[c][j] = v;
             }
     } else S.last_def = read_number_in_batch;
-    while (!S.stack.empty() && S.stack.back().npos <= npos) S.stack.pop_back();
-    S.stack.push_back({npos, std::string(seq, len)});
+    std::string keep;  // (the storage of a popped entry is used again: one entry is popped and one pushed per read of a fixed-length file)
+    while (!S.stack.empty() && S.stack.back().npos <= npos) { keep.swap(S.stack.back().seq); S.stack.pop_back(); }
+    keep.assign(seq, len);
+    S.stack.push_back({npos, std::move(keep)});
     return stale;
 }
 
