@@ -59,6 +59,7 @@ struct DevCtx {
     const uint32_t *kmer_off, *kmer_nfwd, *locs;
     const uint64_t *flank_a, *flank_b;  // 32 reference bases after / before each index entry's seed
     uint32_t max_kmer_num;
+    uint32_t heavy_m;     // HEAVY kernels: a list of at least this many entries is streamed on its own through the three-window test (heavy_mode)
     uint32_t win2_min_T;  // a mode's stream of at least this many candidates tests filter survivors against the second window (process_read); ~0u = never
     uint32_t K, I, max_num_hits, chains, randseed, gap, gap_edge, n_mis, stream_mode, report_repeat_hits;
     const uint8_t *tables;  // alphabet, rev_alphabet, reg_alphabet, alphabet_mread, rev_alphabet_mread
@@ -224,8 +225,16 @@ struct GapLds<NWT, true> {
     SurvEnt surv[128];            // the candidates the flank tests could not rule out, in visitation order
 };
 
-template <int NWT, bool GAP>
-struct WaveLds : GapLds<NWT, GAP> {
+// what only the HEAVY kernels keep per wave: the candidates that passed the stream's window tests, in visitation order, scored 64 at a time
+template <bool HEAVY>
+struct HeavyLds {};
+template <>
+struct HeavyLds<true> {
+    SurvEnt surv[128];  // meta = reference strand | read chain << 1
+};
+
+template <int NWT, bool GAP, bool HEAVY = false>
+struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY> {
     static constexpr int NW = NWT;
     static constexpr int MAXPOS = NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
@@ -239,7 +248,7 @@ struct WaveLds : GapLds<NWT, GAP> {
     uint32_t rno[WORK_CHUNK];      // their read numbers (consecutive, or taken from the pipeline's list)
     basal_read desc[WORK_CHUNK];   // the descriptors of the chunk of reads this wave took from the queue
     basal_result res[WORK_CHUNK];  // and their results, written out together when the chunk is done
-    uint16_t nhit[2][16];  // x_cur_n_hit[chain][level]
+    uint32_t nhit[2][16];  // x_cur_n_hit[chain][level]
     uint8_t start_arr[2][16];
     uint8_t order[2][16];
 };
@@ -907,7 +916,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     uint32_t tot;
     {
         uint32_t a = L.nhit[chain][w] + 1u;
-        if (lane0(lane)) L.nhit[chain][w] = (uint16_t)a;
+        if (lane0(lane)) L.nhit[chain][w] = a;
         tot = rfl(a + L.nhit[chain ^ 1][w]);  // the same in every lane; says so to the compiler (st.thr and the caller's loop exits stay scalar)
     }
     wave_sync();
@@ -969,11 +978,300 @@ __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L
     return c;
 }
 
+
+// ---- HEAVY kernels: bulk hit bookkeeping and the streaming of long lists ----------------------------------------------------------------
+// Is `key` among the log records kept in memory (64 .. nlog-1)? Wave-uniform; four loads in flight per round trip.
+__device__ bool log_has_key(const HitState &st, const basal_hit *log, uint64_t key, int lane) {
+    for (uint32_t base = 64; base < st.nlog; base += 256) {
+        bool d = false;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t idx = base + 64 * u + (uint32_t)lane;
+            const basal_hit h = log[idx < st.nlog ? idx : 0];  // (record 0 of the memory log is never written: its slot belongs to the registers)
+            d |= idx < st.nlog && hit_key(h.chr >> 1, h.loc, h.gap_size != 0) == key;
+        }
+        if (ballot(d)) return true;
+    }
+    return false;
+}
+
+// int2hit + AddHit (align.cpp:319-346, align.h:329-347) for up to 64 scored candidates AT ONCE, lane order = visitation order.
+// The sequential state machine is only order-sensitive at duplicates and where a level reaches the -w cap, so:
+//   * every lane places its own hit (contig search, strand flip, bounds) and forms its key -- none of that depends on the state;
+//   * of the lanes whose count is within the threshold, the ones whose key is already stored (the 64 records in registers by one compare
+//     + ballot per lane, the memory part behind the Bloom filter) or equals the key of an earlier such lane are duplicates;
+//   * per level present, the running total reaches the cap at the lane that holds the (cap - total)-th new hit of that level; the first
+//     such lane over all levels ends the segment: everything up to and including it is appended with one permute / one store, the level
+//     counts grow by popcounts, and the threshold drops to that level - 1 (level 0: SnpAlign stops);
+//   * the lanes after it are looked at again under the new threshold (acceptance is monotone in it).
+// Returns true when SnpAlign must stop.
+template <class LDS>
+__device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log, const ReadCtx &rc, bool active, uint32_t loc, uint32_t strand, uint32_t chain,
+                         uint32_t mm, uint32_t mode, uint32_t r, int lane) {
+    uint64_t pend = ballot(active && mm <= st.thr);
+    if (!pend) return false;
+    const uint64_t lt = (1ULL << lane) - 1;
+    // int2hit's search of ref_anchor (align.cpp:325-329): the largest contig whose anchor is <= loc, 0 if none. s_anchor holds the whole
+    // table (<= 64 contigs) or 64 evenly spaced pivots of it (the search then ends in the stretch of the table between two pivots).
+    const uint32_t nc = COLD(ncontig);
+    const uint32_t pstride = (nc + 63) / 64;  // 1 for <= 64 contigs
+    uint32_t left;
+    {
+        uint32_t lo = 0, hi = (nc + pstride - 1) / pstride;
+#pragma unroll 1
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1, ge = s_anchor[mid & 63] <= loc;
+            lo = go && ge ? mid : lo;
+            hi = go && !ge ? mid : hi;
+        }
+        left = lo;
+        if (nc > 64) {
+            lo = left * pstride;
+            hi = lo + pstride < nc ? lo + pstride : nc;
+            while (ballot(hi - lo > 1)) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const bool go = hi - lo > 1, ge = COLDP(const uint32_t, ref_anchor)[mid < nc ? mid : 0] <= loc;
+                lo = go && ge ? mid : lo;
+                hi = go && !ge ? mid : hi;
+            }
+            left = lo;
+        }
+    }
+    const uint32_t chr = (left * 2 + strand) & 0x3FFFF;
+    const uint32_t wc = chr >> 1;  // the 18-bit wrap of gHit.chr: title[] is read at the WRAPPED contig, the anchor at the true one (see add_hit)
+    uint32_t anchor, csize, rcoff;
+    // (each branch pins its loads with an empty asm: sunk into the `if (strand)` below, the choice between an LDS and a global pointer would be a flat load)
+    if (nc <= 64) { anchor = s_anchor[left & 63]; csize = s_csize[left & 63]; rcoff = s_rcoff[left & 63]; asm volatile("" : "+v"(rcoff), "+v"(csize), "+v"(anchor)); }
+    else {
+        const uint32_t wci = wc < nc ? wc : 0;
+        anchor = COLDP(const uint32_t, ref_anchor)[left]; csize = COLDP(const uint32_t, contig_size)[wci]; rcoff = COLDP(const uint32_t, rc_offset)[wci];
+        asm volatile("" : "+v"(rcoff), "+v"(csize), "+v"(anchor));
+    }
+    uint32_t l = loc - anchor;
+    if (strand) l = rcoff - rc.len - l;
+    pend &= ballot((int)l >= 0 && l + rc.len <= csize);  // AddHit's two bounds (align.h:330-331)
+    const uint64_t key = hit_key(chr >> 1, l, false);
+    const uint32_t bh = bloom_hash(key), b1 = bh & 2047u, b2 = (bh >> 11) & 2047u;
+    HitWords u;
+    u.h.loc = l; u.h.chr = chr; u.h.gap_size = 0; u.h.strand = (uint8_t)(((strand << 1) | chain) & 3);
+    u.h.gap_pos = (uint16_t)(strand ? rc.len & 0x1FFu : 0u);  // int2hit mirrors gap_pos on the reverse strand even without a gap (align.cpp:341)
+    u.h.level = (uint8_t)mm; u.h.chain = (uint8_t)chain; u.h.mode = (uint8_t)mode; u.h.pad = 0;
+    const uint32_t cap = COLD(max_num_hits), spw = COLD(scratch_per_wave);
+    for (uint32_t spin = 0;; spin++) {
+        if (spin > 64) { guard_idx(cx, G_WATCHDOG, 0x40000u | spin, 0, r); return true; }
+        const uint64_t acc = pend & ballot(mm <= st.thr);
+        if (!acc) return false;
+        // duplicates: of the stored records, and of earlier lanes of this segment
+        const uint64_t regk = hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0);
+        const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
+        bool maybe = false;
+        if (st.nlog > 64) {
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b1 >> 5) << 2), (int)st.bloom), w2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b2 >> 5) << 2), (int)st.bloom);
+            maybe = ((w1 >> (b1 & 31)) & (w2 >> (b2 & 31)) & 1u) != 0;
+        }
+        const uint64_t maybe_m = ballot(maybe);
+        uint64_t dup = 0;
+        for (uint64_t a = acc; a; a &= a - 1) {
+            const int la = __ffsll((unsigned long long)a) - 1;
+            const uint64_t bit = 1ULL << la;
+            if (dup & bit) continue;
+            const uint64_t kb = rdlane64(key, la);
+            bool known = (ballot(regk == kb) & in_regs) != 0;
+            if (!known && (maybe_m & bit)) known = log_has_key(st, log, kb, lane);
+            if (known) dup |= bit;
+            dup |= ballot(key == kb) & a & ~bit;
+        }
+        const uint64_t newm = acc & ~dup;
+        // the first lane at which a level's total reaches the cap
+        uint32_t xlane = 64, xlevel = 0;
+        {
+            const uint32_t totv = lane < 16 ? L.nhit[0][lane] + L.nhit[1][lane] : 0;
+            for (uint64_t rem = newm; rem;) {
+                const uint32_t w = rdlane(mm, __ffsll((unsigned long long)rem) - 1);
+                const uint64_t mw = ballot(mm == w) & newm;
+                rem &= ~mw;
+                const uint32_t tw = rdlane(totv, (int)(w & 15));
+                const uint32_t room = tw < cap ? cap - tw : 1;
+                if ((uint32_t)__popcll(mw) >= room) {
+                    const uint64_t hm = ballot((uint32_t)__popcll(mw & lt) + 1 == room) & mw;
+                    const uint32_t xl = (uint32_t)__ffsll((unsigned long long)hm) - 1;
+                    if (xl < xlane) { xlane = xl; xlevel = w; }
+                }
+            }
+        }
+        const uint64_t upto = xlane < 63 ? (2ULL << xlane) - 1 : ~0ULL;
+        const uint64_t segm = newm & upto;
+        if (segm) {
+            const bool mine = (segm >> lane) & 1;
+            const uint32_t n0 = st.nlog, cnt = (uint32_t)__popcll(segm), pos = n0 + (uint32_t)__popcll(segm & lt);
+            if (n0 < 64) {  // records 0..63 live in registers, record i in lane i: every new hit goes to the lane of its position
+                // (lanes with nothing to send aim at a lane outside [n0, n0 + cnt): lane 0 if n0 > 0, else lane 63 -- when the range is all 64 lanes every lane sends)
+                const uint32_t dst = (mine && pos < 64) ? pos : (n0 ? 0u : 63u);
+                const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)u.w[0]), r1 = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)u.w[1]),
+                               r2 = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)u.w[2]), r3 = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)u.w[3]);
+                if ((uint32_t)lane >= n0 && (uint32_t)lane < n0 + cnt) { st.d0 = r0; st.d1 = r1; st.d2 = r2; st.d3 = r3; }
+            }
+            const uint64_t inmem = ballot(mine && pos >= 64 && pos < spw);
+            if (inmem) {
+                if ((inmem >> lane) & 1) log[pos] = u.h;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
+                for (uint64_t a = inmem; a; a &= a - 1) {
+                    const int la = __ffsll((unsigned long long)a) - 1;
+                    const uint32_t c1 = rdlane(b1, la), c2 = rdlane(b2, la);
+                    if ((uint32_t)lane == (c1 >> 5)) st.bloom |= 1u << (c1 & 31);
+                    if ((uint32_t)lane == (c2 >> 5)) st.bloom |= 1u << (c2 & 31);
+                }
+            }
+            if (mine) atomicAdd(&L.nhit[chain][mm & 15], 1u);
+            st.nlog = n0 + cnt < spw ? n0 + cnt : spw;
+            wave_sync();
+        }
+        if (xlane >= 64) return false;
+        if (xlevel == 0) return true;
+        st.thr = xlevel - 1;
+        pend &= ~upto;
+    }
+}
+
+// the candidates in L.surv[0 .. min(nsurv, 64)): all their reference words in one round trip, exact count (CountMismatch*), bulk bookkeeping
+template <int NWT, bool NEWRULE, class LDS>
+__device__ bool heavy_flush(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t mode, uint32_t &nsurv, uint32_t r, int lane PH_PARAM) {
+    const uint32_t batch = nsurv < 64 ? nsurv : 64;
+    const bool active = (uint32_t)lane < batch;
+    uint32_t loc = 0, strand = 0, chain = 0, mm = 0xffff;
+    if (active) {
+        const SurvEnt sv = L.surv[lane];
+        loc = sv.loc; strand = sv.meta & 1u; chain = (sv.meta >> 1) & 1u;
+        if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
+        const uint32_t off2 = (loc & 31) * 2, nw = (rc.len + (loc & 31) + 31) / 32;
+        mm = count_mismatch<NWT, NEWRULE>((strand ? cx.xref[1] : cx.xref[0]) + (loc >> 5), L.q[chain], off2, nw, st.thr, rc.n_count);
+    }
+    PH(PH_SCORE);
+    const bool stop = bulk_add(cx, L, st, log, rc, active, loc, strand, chain, mm, mode, r, lane);
+    PH(PH_E1);
+    const uint32_t rest = nsurv - batch;  // drop the batch from the front of the list
+    SurvEnt v = {0, 0};
+    if ((uint32_t)lane < rest) v = L.surv[batch + lane];
+    wave_sync();
+    if ((uint32_t)lane < rest) L.surv[lane] = v;
+    nsurv = rest;
+    wave_sync();
+    return stop;
+}
+
+// One mode of SnpAlign (align.cpp:274-316) in the HEAVY kernels. The mode's stream is cut into stretches of short lists, which go through
+// the packed chunks of the standard kernel (64 consecutive stream positions, one window test), and long lists (>= cx.heavy_m entries),
+// each streamed on its own: every lane of a chunk then shares the seed, so its read windows sit in scalar registers, the loads are
+// straight runs of the list, and three windows (up to 96 of the read's bases off the seed) are tested from the coalesced stream. What
+// passes is appended IN ORDER to L.surv and scored 64 at a time on full waves (heavy_flush). Returns true when SnpAlign must stop.
+template <int NWT, bool NEWRULE, class LDS>
+__device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t mode, uint32_t inc, uint32_t e_m, uint32_t nent,
+                           uint32_t T, uint32_t r, int lane PH_PARAM) {
+    const uint64_t lt = (1ULL << lane) - 1;
+    const uint64_t end_mask = nent > 1 ? (1ULL << (nent - 1)) - 1 : 0;
+    const uint32_t nlocs_u = COLD(nlocs);
+    const unsigned long long stride = (unsigned long long)nlocs_u + 64;
+    uint32_t nsurv = 0;
+    bool stop = false;
+    uint64_t hv = ballot((uint32_t)lane < nent && e_m >= cx.heavy_m);
+    uint32_t tcur = 0;
+    for (uint32_t guard_it = 0; guard_it <= 64 && !stop; guard_it++) {
+        const int eh = hv ? __ffsll((unsigned long long)hv) - 1 : -1;
+        const uint32_t tend = eh >= 0 ? rdlane(inc - e_m, eh) : T;
+        if (tcur < tend) {  // a stretch of short lists
+            ChunkLoads nxt = issue_chunk<false>(cx, L, inc, end_mask, tcur, tend, lane, nlocs_u, stride, r);
+            for (uint32_t t0 = tcur; t0 < tend && !stop;) {
+                const ChunkLoads cur = nxt;
+                const bool active = t0 + (uint32_t)lane < tend;
+                t0 += 64;
+                if (t0 < tend) nxt = issue_chunk<false>(cx, L, inc, end_mask, t0, tend, lane, nlocs_u, stride, r);
+                bool alive = false;
+                SurvEnt sv = {0, 0};
+                if (active) {
+                    const uint32_t ei = cur.ei, hcs = L.ent[ei].hcs, e_nfwd = L.ent[ei].nfwd;
+                    const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm, e_fc = NEWRULE ? L.ent[ei].fc : 0;
+                    alive = rc.n_count + XM64(cmp_word<NEWRULE>(e_fr, e_fc, cur.f) & e_fm) <= st.thr;
+                    sv.loc = cur.loc_raw - (hcs & 0xffffu);
+                    sv.meta = (uint32_t)(cur.jj >= e_nfwd) | (((hcs >> 16) & 1u) << 1);
+                }
+                PH(PH_FILTER);
+                const uint64_t mk = ballot(alive);
+                if (mk) {
+                    if (alive) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
+                    nsurv += (uint32_t)__popcll(mk);
+                    wave_sync();
+                    if (nsurv >= 64) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
+                }
+            }
+            if (stop) break;
+        }
+        if (eh < 0) break;
+        {   // one long list: entry eh
+            const uint32_t l_off = rfl(L.ent[eh].off), l_m = rfl(L.ent[eh].m), l_nfwd = rfl(L.ent[eh].nfwd), l_jj0 = rfl(L.ent[eh].jj0), l_hcs = rfl(L.ent[eh].hcs);
+            const uint32_t h = l_hcs & 0xffffu, chain = (l_hcs >> 16) & 1u, side = l_hcs >> 17;
+            // the read's windows opposite the 32 bases after the seed, the 32 before it, and the next 32 on the side with more read bases
+            uint64_t ra, ma, ca, rb, mb, cb, rf, mf, cf;
+            plane_window3<NWT, NEWRULE>(L.q[chain], (int)(h + cx.K), ra, ma, ca);
+            plane_window3<NWT, NEWRULE>(L.q[chain], (int)h - 32, rb, mb, cb);
+            plane_window3<NWT, NEWRULE>(L.q[chain], side ? (int)h - 64 : (int)(h + cx.K + 32), rf, mf, cf);
+            ra = rdlane64(ra, 0); ma = rdlane64(ma, 0); rb = rdlane64(rb, 0); mb = rdlane64(mb, 0); rf = rdlane64(rf, 0); mf = rdlane64(mf, 0);
+            if (NEWRULE) { ca = rdlane64(ca, 0); cb = rdlane64(cb, 0); cf = rdlane64(cf, 0); }
+            const bool has_a = ma != 0, has_b = mb != 0, has_f = mf != 0;  // (a window off the read costs no load)
+            const uint32_t *Lc = cx.locs + l_off;
+            const uint64_t *Fa = cx.flank_a + l_off, *Fb = Fa + stride, *Ff = Fa + (2ULL + side) * stride;
+            struct HL { uint32_t loc; uint64_t a, b, f; };
+            auto issue = [&](uint32_t p0) {
+                HL c = {0, 0, 0, 0};
+                const uint32_t p = p0 + (uint32_t)lane;
+                if (p < l_m) {
+                    uint32_t jj = l_jj0 + p;
+                    if (jj >= l_m) jj -= l_m;
+                    c.loc = Lc[jj];
+                    if (has_a) c.a = Fa[jj];
+                    if (has_b) c.b = Fb[jj];
+                    if (has_f) c.f = Ff[jj];
+                }
+                return c;
+            };
+            HL nx = issue(0);
+            for (uint32_t p0 = 0; p0 < l_m && !stop; p0 += 64) {
+                const HL cur = nx;
+                if (p0 + 64 < l_m) nx = issue(p0 + 64);
+                const uint32_t p = p0 + (uint32_t)lane;
+                uint32_t jj = l_jj0 + p;
+                if (jj >= l_m) jj -= l_m;
+                const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ra, ca, cur.a) & ma) + XM64(cmp_word<NEWRULE>(rb, cb, cur.b) & mb) +
+                                    XM64(cmp_word<NEWRULE>(rf, cf, cur.f) & mf);
+                const bool alive = p < l_m && lb <= st.thr;
+                PH(PH_FILTER);
+                const uint64_t mk = ballot(alive);
+                if (mk) {
+                    if (alive) {
+                        SurvEnt sv;
+                        sv.loc = cur.loc - h;
+                        sv.meta = (uint32_t)(jj >= l_nfwd) | (chain << 1);
+                        L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
+                    }
+                    nsurv += (uint32_t)__popcll(mk);
+                    wave_sync();
+                    if (nsurv >= 64) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
+                }
+            }
+        }
+        tcur = rdlane(inc, eh);
+        hv &= hv - 1;
+    }
+    while (!stop && nsurv) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
+    return stop;
+}
+
 // ---- one read ----------------------------------------------------------------------------------
-template <int NWT, bool NEWRULE, bool GAP>
-__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
+template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
+__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
                              const uint32_t *pre, int pre_c, int lane PH_PARAM) {
-    using LDS = WaveLds<NWT, GAP>;
+    using LDS = WaveLds<NWT, GAP, HEAVY>;
+    static_assert(!(GAP && HEAVY), "the HEAVY path is the non-GAP kernels'");
     const bool allmodes = (rd.readset & BASAL_READ_ALLMODES) != 0;  // a PE mate: PairAlign::RunAlign drives the modes
     rd.readset &= 0x7f;
     basal_result res;
@@ -984,38 +1282,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         if (lane0(lane)) L.res[chunk_slot] = res;
         return;
     }
-#ifdef BASAL_PERTURB_VALU  // sensitivity experiment only: extra VALU work per read
-    {
-        uint32_t x = lane;
-#pragma unroll 1
-        for (int i = 0; i < BASAL_PERTURB_VALU / 4; i++) asm volatile("v_add_u32 %0, %0, 1\n v_xor_b32 %0, %0, 3\n v_add_u32 %0, %0, 5\n v_xor_b32 %0, %0, 7" : "+v"(x));
-        if (x == 0x12345) L.nhit[0][0] = 1;
-    }
-#endif
-#ifdef BASAL_PERTURB_SALU  // sensitivity experiment only: extra scalar ALU work per read
-    {
-        uint32_t x = r;
-#pragma unroll 1
-        for (int i = 0; i < BASAL_PERTURB_SALU / 4; i++)
-            asm volatile("s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 3\n s_add_u32 %0, %0, 5\n s_xor_b32 %0, %0, 7" : "+s"(x) : : "scc");
-        if (x == 0x12345) L.nhit[0][0] = 1;
-    }
-#endif
-#ifdef BASAL_PERTURB_LDS  // sensitivity experiment only: extra LDS reads per read
-    {
-        uint32_t x = 0;
-#pragma unroll 1
-        for (int i = 0; i < BASAL_PERTURB_LDS; i++) x += ((volatile uint32_t *)L.seed[0])[(lane + i) & 63];
-        if (x == 0x12345) L.nhit[0][0] = 1;
-    }
-#endif
-#ifdef BASAL_PERTURB_MEM  // sensitivity experiment only: extra independent random sector reads per read
-    {
-        uint32_t h = (r * 64u + (uint32_t)lane) * 2654435761u;
-        uint32_t x = 0;
-        if (lane < BASAL_PERTURB_MEM) x = cx.locs[h % COLD(nlocs)];
-        if (x == 0xfffffff1u) L.nhit[0][0] = 1;
-    }
+#if defined(BASAL_PERTURB_VALU) || defined(BASAL_PERTURB_SALU) || defined(BASAL_PERTURB_LDS) || defined(BASAL_PERTURB_MEM)
+#include "basal_core_diag.inc"  // sensitivity experiments only
 #endif
     ReadCtx rc;
     uint32_t slot = rd.readset == 2 ? 1 : 0;
@@ -1127,6 +1395,9 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
         const uint32_t T = rdlane(inc, (int)nent - 1);
         PH(PH_MODE);
 
+        if constexpr (HEAVY) {
+            done = heavy_mode<NWT, NEWRULE>(cx, L, st, log, rc, mode, inc, e_m, nent, T, r, lane PH_ARG);
+        } else {
         // Non-GAP: 64 candidates of the stream per iteration. GAP: the flank tests run on the stream, the candidates they
         // cannot rule out are compacted (order kept) into L.surv and scored + gap-searched 64 at a time, so the expensive
         // part runs on full waves instead of on the ~quarter of the lanes that survive.
@@ -1389,6 +1660,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
                 wave_sync();
             }
         }
+        }  // !HEAVY
         // RunAlign: stop once any level <= mode holds a hit (align.cpp:462); `done` = AddHit said stop.
         // For a PE mate the stop only ends this SnpAlign call; the next mode still runs (pairs.cpp:164-174).
         if (allmodes) done = false;
@@ -1471,14 +1743,17 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP> &L, const uint8
 #ifndef BASAL_W16G
 #define BASAL_W16G 2
 #endif
-constexpr int waves_per_simd(int nwt, bool gap) {
-    return nwt == 4 ? (gap ? BASAL_W4G : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : BASAL_W8NG) : (gap ? BASAL_W16G : BASAL_W16NG);
+#ifndef BASAL_W4H
+#define BASAL_W4H 6  // HEAVY: the survivor list makes the LDS 24 KB per block (six blocks per CU), and the long-list loop wants its registers
+#endif
+constexpr int waves_per_simd(int nwt, bool gap, bool heavy = false) {
+    return nwt == 4 ? (gap ? BASAL_W4G : heavy ? BASAL_W4H : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : BASAL_W8NG) : (gap ? BASAL_W16G : BASAL_W16NG);
 }
 
-template <int NWT, bool NEWRULE, bool GAP>
-__global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(DevCtx cx) {
+template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
+__global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_kernel(DevCtx cx) {
     __shared__ uint8_t s_tab[5 * 256];
-    __shared__ WaveLds<NWT, GAP> s_w[4];
+    __shared__ WaveLds<NWT, GAP, HEAVY> s_w[4];
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
     s_prof[threadIdx.x >> 4][threadIdx.x & 15] = (uint16_t)profile(threadIdx.x >> 4, threadIdx.x & 15, cx.K, cx.I);
     if (threadIdx.x >= 1 && threadIdx.x <= 16) s_rcp[threadIdx.x] = (65536u + threadIdx.x - 1) / threadIdx.x;
@@ -1487,9 +1762,13 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
         s_rcoff[threadIdx.x] = cx.rc_offset[threadIdx.x];
         s_csize[threadIdx.x] = cx.contig_size[threadIdx.x];
     }
+    if constexpr (HEAVY) {  // more than 64 contigs: 64 evenly spaced pivots of the anchor table (bulk_add's search starts there)
+        const uint32_t ps = (cx.ncontig + 63) / 64;
+        if (threadIdx.x < 64 && cx.ncontig > 64) s_anchor[threadIdx.x] = threadIdx.x * ps < cx.ncontig ? cx.ref_anchor[threadIdx.x * ps] : 0xFFFFFFFFu;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    WaveLds<NWT, GAP> &L = s_w[wv];
+    WaveLds<NWT, GAP, HEAVY> &L = s_w[wv];
     if (lane <= NWT) {  // zero the pad words once
         for (int c = 0; c < 2; c++)
             for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
@@ -1564,7 +1843,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
             uint64_t snap[PH_N];
             for (int i = 0; i < PH_N; i++) snap[i] = phc.acc[i];
 #endif
-            process_read<NWT, NEWRULE, GAP>(cx, L, s_tab, log, r, w - base, rd, pre, pc, lane PH_ARG);
+            process_read<NWT, NEWRULE, GAP, HEAVY>(cx, L, s_tab, log, r, w - base, rd, pre, pc, lane PH_ARG);
 #ifdef BASAL_PHASE_TIMING
             {   // histogram of per-read wave-clocks by power of two (diagnostic build)
                 const uint64_t dtc = __builtin_readcyclecounter() - t_read0;
@@ -1597,9 +1876,10 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP)) void align_kernel(De
 
 typedef void (*kernel_fn)(DevCtx);
 template <int NWT>
-kernel_fn pick_kernel(bool newrule, bool gap) {
-    if (newrule) return gap ? align_kernel<NWT, true, true> : align_kernel<NWT, true, false>;
-    return gap ? align_kernel<NWT, false, true> : align_kernel<NWT, false, false>;
+kernel_fn pick_kernel(bool newrule, bool gap, bool heavy = false) {
+    if (heavy && !gap) return newrule ? align_kernel<NWT, true, false, true> : align_kernel<NWT, false, false, true>;
+    if (newrule) return gap ? align_kernel<NWT, true, true, false> : align_kernel<NWT, true, false, false>;
+    return gap ? align_kernel<NWT, false, true, false> : align_kernel<NWT, false, false, false>;
 }
 
 }  // namespace
@@ -1769,7 +2049,8 @@ extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_
     if (lds_bytes) {
         int nwt = c->nwt ? c->nwt : 4;
         bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
-        kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp) : nwt == 8 ? pick_kernel<8>(nr, gp) : pick_kernel<16>(nr, gp);
+        const bool hv = c->heavy && !gp;
+        kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv) : nwt == 8 ? pick_kernel<8>(nr, gp, hv) : pick_kernel<16>(nr, gp, hv);
         hipFuncAttributes at;
         HIP_TRY(hipFuncGetAttributes(&at, (const void *)k));
         *lds_bytes = (uint32_t)at.sharedSizeBytes;
@@ -1832,12 +2113,18 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     int nwt = max_len <= 128 ? 4 : max_len <= 256 ? 8 : 16;
     c->nwt = nwt;
     bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
-    kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp) : nwt == 8 ? pick_kernel<8>(nr, gp) : pick_kernel<16>(nr, gp);
+    const bool hv = c->heavy && !gp;
+    {
+        const char *e = getenv("BASAL_HEAVY_M");  // (tests: 1 sends every list through the long-list loop)
+        cx.heavy_m = e ? (uint32_t)atoi(e) : 512u;
+        if (cx.heavy_m < 1) cx.heavy_m = 1;
+    }
+    kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv) : nwt == 8 ? pick_kernel<8>(nr, gp, hv) : pick_kernel<16>(nr, gp, hv);
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
     cx.guard = counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
     const char *env = getenv("BASAL_BLOCKS_PER_CU");
-    uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp);
+    uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, hv);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;

@@ -18,6 +18,7 @@ struct basal_core {
     uint64_t nlocs = 0;
     uint32_t total_kmers = 0, max_kmer_num = 0;
     bool have_ref = false, have_index = false;
+    bool heavy = false;  // the index keeps long lists (high cut-off): four flank words per entry, HEAVY kernel instantiation (set by basal_build_flanks)
     uint8_t *d_tables = nullptr;
     // work buffers
     basal_hit *d_scratch = nullptr;

@@ -451,6 +451,8 @@ def main():
         best, cnt, secs_v = ob.align(sb, sd["seq_off"], sd["len"], sd["index"], sd["max_snp"], threads)
         bad = oracle_bridge.differing(timed[:ns], best)
         if len(bad):
+            for i in bad[:8]:
+                log("differs: read %d gpu %r oracle %r" % (i, timed[i], best[i]))
             raise SystemExit("bench: %d of %d sampled reads differ between the GPU path and the CPU oracle -- number withheld" % (len(bad), ns))
 
         class _S:

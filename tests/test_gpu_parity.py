@@ -103,6 +103,26 @@ def test_second_window_on_every_fixture():
     assert m and int(m.group(1)) >= 2 * len(H.SE), r.stdout[-500:]
 
 
+@pytest.mark.parametrize("heavy_m", ["1", "3", "512"])
+def test_heavy_kernels_on_every_fixture(heavy_m):
+    """Cores whose index keeps long lists (a high over-represented-k-mer cut-off: a repeat-rich genome) run the HEAVY instantiation of the
+    non-GAP kernels: long lists streamed on their own through a three-window test, survivors scored 64 at a time, hits booked in bulk
+    (DESIGN 4.1).  No fixture has such an index, so BASAL_HEAVY=1 selects those kernels for every core, and BASAL_HEAVY_M sends every
+    list (1), every list of three or more entries (3: packed stretches and long lists alternate within a mode) or none (512) through the
+    long-list loop: all hit logs must still be the oracle's, all SAMs the golden ones (the -g fixtures keep their GAP kernels)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BASAL_HEAVY="1", BASAL_HEAVY_M=heavy_m)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_hit_logs_match_oracle or test_sam_matches_golden_through_abi or test_small_batches_carry_state"],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 2 * len(H.SE), r.stdout[-500:]
+
+
 @pytest.mark.parametrize("name", H.SE)
 def test_sam_matches_golden_through_abi(name):
     flags = H.MANIFEST[name]["flags"]
