@@ -89,8 +89,15 @@ struct DevCtx {
     const uint32_t *order;
     const uint32_t *n_ptr;
     uint32_t ghost_base;
+    // Two-pass launches of cores whose index keeps long lists (launch_align): pass 1, the standard kernel, sets aside every read that meets a
+    // list of >= heavy_m entries -- (k-mer of that list, read number) appended here -- and pass 2, the HEAVY kernel, aligns those reads in
+    // the order of their k-mers, so that the waves running at any moment stream the same few lists and find them in the caches.
+    uint32_t *defer_keys, *defer_reads;
+    unsigned int *defer_count;
+    uint32_t work_chunk;  // reads a wave takes from the queue per atomic (<= WORK_CHUNK)
 };
 
+#define BASAL_READ_DEFERRED 3  // internal: pass 1 left the read to pass 2, which overwrites this record
 enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 5, G_KMER2 = 6, G_WATCHDOG = 7 };
 
 // Diagnostic build only (-DBASAL_PHASE_TIMING, `make prof`): per-phase shader-clock totals, summed over all waves
@@ -230,7 +237,9 @@ template <bool HEAVY>
 struct HeavyLds {};
 template <>
 struct HeavyLds<true> {
-    SurvEnt surv[128];  // meta = reference strand | read chain << 1
+    SurvEnt surv[128];    // meta = reference strand | read chain << 1
+    uint32_t bloom[128];  // a 4096-bit Bloom filter over the keys of ALL stored hits of the read (bulk_add)
+    uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
 
 template <int NWT, bool GAP, bool HEAVY = false>
@@ -1052,7 +1061,7 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
     if (strand) l = rcoff - rc.len - l;
     pend &= ballot((int)l >= 0 && l + rc.len <= csize);  // AddHit's two bounds (align.h:330-331)
     const uint64_t key = hit_key(chr >> 1, l, false);
-    const uint32_t bh = bloom_hash(key), b1 = bh & 2047u, b2 = (bh >> 11) & 2047u;
+    const uint32_t bh = bloom_hash(key), b1 = bh & 4095u, b2 = (bh >> 12) & 4095u, bk = bh >> 27;
     HitWords u;
     u.h.loc = l; u.h.chr = chr; u.h.gap_size = 0; u.h.strand = (uint8_t)(((strand << 1) | chain) & 3);
     u.h.gap_pos = (uint16_t)(strand ? rc.len & 0x1FFu : 0u);  // int2hit mirrors gap_pos on the reverse strand even without a gap (align.cpp:341)
@@ -1062,25 +1071,41 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
         if (spin > 64) { guard_idx(cx, G_WATCHDOG, 0x40000u | spin, 0, r); return true; }
         const uint64_t acc = pend & ballot(mm <= st.thr);
         if (!acc) return false;
-        // duplicates: of the stored records, and of earlier lanes of this segment
-        const uint64_t regk = hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0);
-        const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
-        bool maybe = false;
-        if (st.nlog > 64) {
-            const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b1 >> 5) << 2), (int)st.bloom), w2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((b2 >> 5) << 2), (int)st.bloom);
-            maybe = ((w1 >> (b1 & 31)) & (w2 >> (b2 & 31)) & 1u) != 0;
-        }
-        const uint64_t maybe_m = ballot(maybe);
         uint64_t dup = 0;
-        for (uint64_t a = acc; a; a &= a - 1) {
-            const int la = __ffsll((unsigned long long)a) - 1;
-            const uint64_t bit = 1ULL << la;
-            if (dup & bit) continue;
-            const uint64_t kb = rdlane64(key, la);
-            bool known = (ballot(regk == kb) & in_regs) != 0;
-            if (!known && (maybe_m & bit)) known = log_has_key(st, log, kb, lane);
-            if (known) dup |= bit;
-            dup |= ballot(key == kb) & a & ~bit;
+        // Duplicates among the lanes themselves, in rounds: every lane still open aims at the bucket of its key's hash, the lowest lane of
+        // a bucket is the first of its key; the others compare their key with that lane's -- equal: a duplicate of an earlier lane; not
+        // equal (two keys in one bucket): open for the next round. Equal keys share a bucket, so nothing is missed.
+        if (acc & (acc - 1)) {
+            for (uint64_t open = acc; open;) {
+                if (lane < 32) L.bucket[lane] = 0xFFFFFFFFu;
+                wave_sync();
+                const bool in = (open >> lane) & 1;
+                if (in) atomicMin(&L.bucket[bk], (uint32_t)lane);
+                wave_sync();
+                const uint32_t w = in ? L.bucket[bk] & 63u : (uint32_t)lane;
+                const uint32_t klo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)(uint32_t)key), khi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)(uint32_t)(key >> 32));
+                const bool same = klo == (uint32_t)key && khi == (uint32_t)(key >> 32);
+                const uint64_t first_m = ballot(w == (uint32_t)lane) & open, dup_m = ballot(w != (uint32_t)lane && same) & open;
+                dup |= dup_m;
+                open &= ~(first_m | dup_m);
+            }
+        }
+        // Duplicates of stored hits: a key the Bloom filter (all stored keys of the read) has not seen is new; the few it may have seen
+        // are looked up one by one -- the 64 records in registers with one compare + ballot, the rest of the log by scanning it.
+        {
+            const bool maybe = st.nlog && ((L.bloom[b1 >> 5] >> (b1 & 31)) & (L.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
+            uint64_t chk = ballot(maybe) & acc & ~dup;
+            if (chk) {
+                const uint64_t regk = hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0);
+                const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
+                for (; chk; chk &= chk - 1) {
+                    const int la = __ffsll((unsigned long long)chk) - 1;
+                    const uint64_t kb = rdlane64(key, la);
+                    bool known = (ballot(regk == kb) & in_regs) != 0;
+                    if (!known && st.nlog > 64) known = log_has_key(st, log, kb, lane);
+                    if (known) dup |= 1ULL << la;
+                }
+            }
         }
         const uint64_t newm = acc & ~dup;
         // the first lane at which a level's total reaches the cap
@@ -1116,14 +1141,12 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
             if (inmem) {
                 if ((inmem >> lane) & 1) log[pos] = u.h;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
-                for (uint64_t a = inmem; a; a &= a - 1) {
-                    const int la = __ffsll((unsigned long long)a) - 1;
-                    const uint32_t c1 = rdlane(b1, la), c2 = rdlane(b2, la);
-                    if ((uint32_t)lane == (c1 >> 5)) st.bloom |= 1u << (c1 & 31);
-                    if ((uint32_t)lane == (c2 >> 5)) st.bloom |= 1u << (c2 & 31);
-                }
             }
-            if (mine) atomicAdd(&L.nhit[chain][mm & 15], 1u);
+            if (mine) {
+                atomicOr(&L.bloom[b1 >> 5], 1u << (b1 & 31));
+                atomicOr(&L.bloom[b2 >> 5], 1u << (b2 & 31));
+                atomicAdd(&L.nhit[chain][mm & 15], 1u);
+            }
             st.nlog = n0 + cnt < spw ? n0 + cnt : spw;
             wave_sync();
         }
@@ -1244,6 +1267,14 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ra, ca, cur.a) & ma) + XM64(cmp_word<NEWRULE>(rb, cb, cur.b) & mb) +
                                     XM64(cmp_word<NEWRULE>(rf, cf, cur.f) & mf);
                 const bool alive = p < l_m && lb <= st.thr;
+#ifdef BASAL_PHASE_TIMING  // long-list chunks; lanes alive after the two near windows; 16-lane groups (128-byte lines of the far words) with such a lane; survivors
+                {
+                    const uint64_t ab = ballot(p < l_m && rc.n_count + XM64(cmp_word<NEWRULE>(ra, ca, cur.a) & ma) + XM64(cmp_word<NEWRULE>(rb, cb, cur.b) & mb) <= st.thr);
+                    phc.n_chunks++; phc.n_alive += (uint32_t)__popcll(ab);
+                    phc.n_bigchunks += ((ab & 0xffffULL) != 0) + ((ab & 0xffff0000ULL) != 0) + ((ab & 0xffff00000000ULL) != 0) + ((ab & 0xffff000000000000ULL) != 0);
+                    phc.n_bigalive += (uint32_t)__popcll(ballot(alive));
+                }
+#endif
                 PH(PH_FILTER);
                 const uint64_t mk = ballot(alive);
                 if (mk) {
@@ -1319,6 +1350,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
         wave_sync();
     }
     if (lane < 32) L.nhit[lane >> 4][lane & 15] = 0;
+    if constexpr (HEAVY) { L.bloom[lane] = 0; L.bloom[lane + 64] = 0; }
     wave_sync();
     reorder_seed(cx, L, rc, lane, so0, so1);
     res.start_off[0] = (uint8_t)so0;
@@ -1336,7 +1368,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
     bool done = false;
     for (uint32_t mode = 0; mode < rc.nseg && !done; mode++) {
         // the seeds of this mode, chain-major then phase (the order SnpAlign visits them, align.cpp:275-279)
-        uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0;
+        uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0, e_sd = 0;
         if ((uint32_t)lane < nent) {
             const uint32_t c = ent_c, i = ent_i;
             if (rc.on(c)) {
@@ -1347,6 +1379,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
                 if (sd >= COLD(total_kmers)) sd = (uint32_t)guard_idx(cx, G_KMER2, 0x80000000u | pos | (seg << 16) | (c << 24) | (mode << 26), 0, r);
                 if (m != 0 && m <= cx.max_kmer_num) {
                     e_m = m;
+                    e_sd = sd;
                     e_off = cx.kmer_off[sd];
                     e_nfwd = cx.kmer_nfwd[sd];
                     e_h = pos;
@@ -1395,6 +1428,22 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
         const uint32_t T = rdlane(inc, (int)nent - 1);
         PH(PH_MODE);
 
+        if constexpr (!GAP && !HEAVY) {
+            // pass 1 of a two-pass launch: a read that meets a long list is set aside for the HEAVY kernel (nothing of it has left the wave yet)
+            if (COLDP(uint32_t, defer_keys) != nullptr) {
+                const uint64_t hv = ballot((uint32_t)lane < nent && e_m >= COLD(heavy_m));
+                if (hv) {
+                    const uint32_t key = rdlane(e_sd, __ffsll((unsigned long long)hv) - 1);
+                    if (lane0(lane)) {
+                        const uint32_t at = atomicAdd(COLDP(unsigned int, defer_count), 1u);
+                        if (at < cx.n) { COLDP(uint32_t, defer_keys)[at] = key; COLDP(uint32_t, defer_reads)[at] = r; }
+                    }
+                    res.status = BASAL_READ_DEFERRED;
+                    if (lane0(lane)) L.res[chunk_slot] = res;
+                    return;
+                }
+            }
+        }
         if constexpr (HEAVY) {
             done = heavy_mode<NWT, NEWRULE>(cx, L, st, log, rc, mode, inc, e_m, nent, T, r, lane PH_ARG);
         } else {
@@ -1802,12 +1851,13 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
         // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
         if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(ballot(1)), 0, iter); break; }
         uint32_t base = 0;
-        if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)WORK_CHUNK);
+        const uint32_t take = COLD(work_chunk);
+        if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)take);
         base = rfl(base);
         PH(PH_QUEUE);
         if (base >= n_items) break;
         if (iter > n_items) { guard_idx(cx, G_WATCHDOG, iter, 0, base); break; }
-        const uint32_t end = base + WORK_CHUNK < n_items ? base + WORK_CHUNK : n_items;
+        const uint32_t end = base + take < n_items ? base + take : n_items;
         // The chunk's descriptors come in with one load, and each read's bytes are requested while the read before it
         // is being aligned, so a read starts on data that is already in registers (2 memory round trips per chunk
         // instead of 2 per read).
@@ -1937,6 +1987,8 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_names); hipFree(c->d_name_off);
+    for (int b = 0; b < 2; b++) { hipFree(c->d_defer_keys[b]); hipFree(c->d_defer_reads[b]); }
+    hipFree(c->d_defer_count); hipFree(c->d_sort_tmp);
     hipFree(c->d_pe_pairs); hipFree(c->d_pe_recs); hipFree(c->d_pe_work); hipFree(c->d_pe_misc);
     hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -2123,23 +2175,56 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
     cx.guard = counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
+    cx.work_chunk = WORK_CHUNK;
     const char *env = getenv("BASAL_BLOCKS_PER_CU");
-    uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, hv);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;
-    c->last_grid = grid;
-    uint32_t need = (n + 4 * WORK_CHUNK - 1) / (4 * WORK_CHUNK);
-    if (grid > need) grid = need;
+    auto grid_for = [&](bool heavy_k, uint32_t chunk) {
+        uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, heavy_k);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;
+        c->last_grid = grid;
+        const uint32_t need = (n + 4 * chunk - 1) / (4 * chunk);
+        return grid > need ? need : grid;
+    };
+    // Two passes (heavy cores, plain launches): the standard kernel first, which sets the reads that meet a long list aside; those, sorted by
+    // the k-mer of that list, then go through the HEAVY kernel -- reads that stream the same lists run side by side and find them in L2 / the
+    // Infinity Cache instead of each pulling megabytes from HBM. BASAL_TWO_PASS=0: one pass of the HEAVY kernel over everything.
+    static const bool two_pass_env = !(getenv("BASAL_TWO_PASS") && atoi(getenv("BASAL_TWO_PASS")) == 0);
+    const bool two_pass = hv && !ex && two_pass_env;
+    if (two_pass) {
+        if ((rc = basal_defer_reserve(c, n))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_defer_count, 0, sizeof(unsigned int), s));
+        HIP_TRY(hipMemsetAsync(c->d_defer_keys[0], 0x04, (size_t)n * 4, s));  // filler key 0x04040404 >= 2^26: behind every k-mer id
+        cx.defer_keys = c->d_defer_keys[0]; cx.defer_reads = c->d_defer_reads[0]; cx.defer_count = c->d_defer_count;
+        k = nwt == 4 ? pick_kernel<4>(nr, gp, false) : nwt == 8 ? pick_kernel<8>(nr, gp, false) : pick_kernel<16>(nr, gp, false);
+    }
+    uint32_t grid = grid_for(hv && !two_pass, WORK_CHUNK);
     if (c->timing && !ex) HIP_TRY(hipEventRecord(c->ev0, s));
     static const bool dbg = getenv("BASAL_DEBUG") != nullptr;
     if (dbg) {
         HIP_TRY(hipStreamSynchronize(s));
-        fprintf(stderr, "[basal debug] launching align kernel NWT=%d newrule=%d gap=%d grid=%u n=%u nstale=%u max_kmer_num=%u nlocs=%llu\n", nwt, (int)nr,
-                (int)gp, grid, n, cx.nstale, cx.max_kmer_num, (unsigned long long)c->nlocs);
+        fprintf(stderr, "[basal debug] launching align kernel NWT=%d newrule=%d gap=%d heavy=%d two_pass=%d grid=%u n=%u nstale=%u max_kmer_num=%u nlocs=%llu\n", nwt, (int)nr,
+                (int)gp, (int)hv, (int)two_pass, grid, n, cx.nstale, cx.max_kmer_num, (unsigned long long)c->nlocs);
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, cx);
     HIP_TRY(hipGetLastError());
+    if (two_pass) {
+        if ((rc = basal_defer_sort(c, n, s))) return rc;
+        HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));
+        DevCtx c2 = cx;
+        c2.defer_keys = c2.defer_reads = nullptr; c2.defer_count = nullptr;
+        c2.order = c->d_defer_reads[1];
+        c2.n_ptr = c->d_defer_count;
+        {
+            const char *e = getenv("BASAL_HEAVY_CHUNK");  // heavy reads run for a long time each: few per queue ticket, so that the launch ends evenly
+            c2.work_chunk = e ? (uint32_t)atoi(e) : 2u;
+            if (c2.work_chunk < 1 || c2.work_chunk > WORK_CHUNK) c2.work_chunk = WORK_CHUNK;
+        }
+        kernel_fn k2 = nwt == 4 ? pick_kernel<4>(nr, gp, true) : nwt == 8 ? pick_kernel<8>(nr, gp, true) : pick_kernel<16>(nr, gp, true);
+        const uint32_t grid2 = grid_for(true, c2.work_chunk);
+        hipLaunchKernelGGL(k2, dim3(grid2), dim3(256), 0, s, c2);
+        HIP_TRY(hipGetLastError());
+    }
     if (dbg) {
         HIP_TRY(hipStreamSynchronize(s));
         fprintf(stderr, "[basal debug] align kernel finished\n");
@@ -2187,7 +2272,7 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
             for (int i = 0; i < PH_N; i++) fprintf(stderr, " %s %.1f%%", nm[i], ht ? 100.0 * ph[PH_N + 4 + 32 + i] / ht : 0.0);
             fprintf(stderr, "  (total %llu)\n", ht);
         }
-        fprintf(stderr, "[basal counts] chunks %llu alive %llu | in modes with >= 1024 candidates: chunks %llu alive %llu\n", ph[PH_N], ph[PH_N + 1], ph[PH_N + 2], ph[PH_N + 3]);
+        fprintf(stderr, "[basal counts] chunks %llu alive %llu | in modes with >= 1024 candidates: chunks %llu alive %llu (HEAVY kernels: long-list chunks, lanes alive after the near windows | 16-lane groups with such a lane, survivors of all windows)\n", ph[PH_N], ph[PH_N + 1], ph[PH_N + 2], ph[PH_N + 3]);
         {
             const unsigned long long *ah = ph + PH_N + 4 + 32 + PH_N;
             fprintf(stderr, "[basal AddHit] calls %llu: off the contig %llu, known (registers) %llu, known (memory log) %llu, new %llu; mean log length at call %.1f, memory scan rounds %llu\n",
