@@ -89,15 +89,8 @@ struct DevCtx {
     const uint32_t *order;
     const uint32_t *n_ptr;
     uint32_t ghost_base;
-    // Two-pass launches of cores whose index keeps long lists (launch_align): pass 1, the standard kernel, sets aside every read that meets a
-    // list of >= heavy_m entries -- (k-mer of that list, read number) appended here -- and pass 2, the HEAVY kernel, aligns those reads in
-    // the order of their k-mers, so that the waves running at any moment stream the same few lists and find them in the caches.
-    uint32_t *defer_keys, *defer_reads;
-    unsigned int *defer_count;
-    uint32_t work_chunk;  // reads a wave takes from the queue per atomic (<= WORK_CHUNK)
 };
 
-#define BASAL_READ_DEFERRED 3  // internal: pass 1 left the read to pass 2, which overwrites this record
 enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 5, G_KMER2 = 6, G_WATCHDOG = 7 };
 
 // Diagnostic build only (-DBASAL_PHASE_TIMING, `make prof`): per-phase shader-clock totals, summed over all waves
@@ -1240,36 +1233,58 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
             plane_window3<NWT, NEWRULE>(L.q[chain], side ? (int)h - 64 : (int)(h + cx.K + 32), rf, mf, cf);
             ra = rdlane64(ra, 0); ma = rdlane64(ma, 0); rb = rdlane64(rb, 0); mb = rdlane64(mb, 0); rf = rdlane64(rf, 0); mf = rdlane64(mf, 0);
             if (NEWRULE) { ca = rdlane64(ca, 0); cb = rdlane64(cb, 0); cf = rdlane64(cf, 0); }
-            const bool has_a = ma != 0, has_b = mb != 0, has_f = mf != 0;  // (a window off the read costs no load)
+            // a window with fewer than six read bases opposite it is not worth its 8 bytes per candidate (off the read altogether: no load either way)
+            if (popc64(ma) < 12) ma = 0;
+            if (popc64(mb) < 12) mb = 0;
+            if (popc64(mf) < 12) mf = 0;
+            const bool has_a = ma != 0, has_b = mb != 0, has_f = mf != 0;
             const uint32_t *Lc = cx.locs + l_off;
             const uint64_t *Fa = cx.flank_a + l_off, *Fb = Fa + stride, *Ff = Fa + (2ULL + side) * stride;
-            struct HL { uint32_t loc; uint64_t a, b, f; };
-            auto issue = [&](uint32_t p0) {
-                HL c = {0, 0, 0, 0};
+            // Two stages of loads per chunk, each issued ahead of its use: the two near windows for every candidate; the far window and the
+            // location only for the lanes the near windows left alive -- a 128-byte line of either is fetched only if one of its 16 (32)
+            // candidates is (40 % of those lines are not, on the hg38-like stand-in: the kernel is bound by HBM bytes).
+            struct S1 { uint64_t a, b; };
+            struct S2 { uint32_t loc; uint64_t f; };
+            auto jj_of = [&](uint32_t p) { uint32_t jj = l_jj0 + p; return jj >= l_m ? jj - l_m : jj; };
+            auto issue1 = [&](uint32_t p0) {
+                S1 c = {0, 0};
                 const uint32_t p = p0 + (uint32_t)lane;
                 if (p < l_m) {
-                    uint32_t jj = l_jj0 + p;
-                    if (jj >= l_m) jj -= l_m;
-                    c.loc = Lc[jj];
+                    const uint32_t jj = jj_of(p);
                     if (has_a) c.a = Fa[jj];
                     if (has_b) c.b = Fb[jj];
+                }
+                return c;
+            };
+            auto eval1 = [&](const S1 &c, uint32_t p0, uint32_t &lb) {
+                lb = rc.n_count + XM64(cmp_word<NEWRULE>(ra, ca, c.a) & ma) + XM64(cmp_word<NEWRULE>(rb, cb, c.b) & mb);
+                return p0 + (uint32_t)lane < l_m && lb <= st.thr;
+            };
+            auto issue2 = [&](uint32_t p0, bool want) {
+                S2 c = {0, 0};
+                if (want) {
+                    const uint32_t jj = jj_of(p0 + (uint32_t)lane);
+                    c.loc = Lc[jj];
                     if (has_f) c.f = Ff[jj];
                 }
                 return c;
             };
-            HL nx = issue(0);
+            S1 n1 = issue1(0), n1b = issue1(64);  // (past the list: nothing is loaded)
+            uint32_t lb_cur;
+            bool alive_cur = eval1(n1, 0, lb_cur);
+            S2 c2 = issue2(0, alive_cur);
+            n1 = n1b;
+            n1b = issue1(128);
             for (uint32_t p0 = 0; p0 < l_m && !stop; p0 += 64) {
-                const HL cur = nx;
-                if (p0 + 64 < l_m) nx = issue(p0 + 64);
-                const uint32_t p = p0 + (uint32_t)lane;
-                uint32_t jj = l_jj0 + p;
-                if (jj >= l_m) jj -= l_m;
-                const uint32_t lb = rc.n_count + XM64(cmp_word<NEWRULE>(ra, ca, cur.a) & ma) + XM64(cmp_word<NEWRULE>(rb, cb, cur.b) & mb) +
-                                    XM64(cmp_word<NEWRULE>(rf, cf, cur.f) & mf);
-                const bool alive = p < l_m && lb <= st.thr;
+                // in flight: c2 = the far words / locations of this chunk, n1 / n1b = the near words of the next two
+                const S1 nn1 = issue1(p0 + 192);
+                uint32_t lb_next;
+                const bool alive_next = eval1(n1, p0 + 64, lb_next);
+                const S2 n2 = issue2(p0 + 64, alive_next);
+                const bool alive = alive_cur && lb_cur + XM64(cmp_word<NEWRULE>(rf, cf, c2.f) & mf) <= st.thr;
 #ifdef BASAL_PHASE_TIMING  // long-list chunks; lanes alive after the two near windows; 16-lane groups (128-byte lines of the far words) with such a lane; survivors
                 {
-                    const uint64_t ab = ballot(p < l_m && rc.n_count + XM64(cmp_word<NEWRULE>(ra, ca, cur.a) & ma) + XM64(cmp_word<NEWRULE>(rb, cb, cur.b) & mb) <= st.thr);
+                    const uint64_t ab = ballot(alive_cur);
                     phc.n_chunks++; phc.n_alive += (uint32_t)__popcll(ab);
                     phc.n_bigchunks += ((ab & 0xffffULL) != 0) + ((ab & 0xffff0000ULL) != 0) + ((ab & 0xffff00000000ULL) != 0) + ((ab & 0xffff000000000000ULL) != 0);
                     phc.n_bigalive += (uint32_t)__popcll(ballot(alive));
@@ -1280,14 +1295,15 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 if (mk) {
                     if (alive) {
                         SurvEnt sv;
-                        sv.loc = cur.loc - h;
-                        sv.meta = (uint32_t)(jj >= l_nfwd) | (chain << 1);
+                        sv.loc = c2.loc - h;
+                        sv.meta = (uint32_t)(jj_of(p0 + (uint32_t)lane) >= l_nfwd) | (chain << 1);
                         L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
                     }
                     nsurv += (uint32_t)__popcll(mk);
                     wave_sync();
                     if (nsurv >= 64) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
                 }
+                c2 = n2; lb_cur = lb_next; alive_cur = alive_next; n1 = n1b; n1b = nn1;
             }
         }
         tcur = rdlane(inc, eh);
@@ -1368,7 +1384,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
     bool done = false;
     for (uint32_t mode = 0; mode < rc.nseg && !done; mode++) {
         // the seeds of this mode, chain-major then phase (the order SnpAlign visits them, align.cpp:275-279)
-        uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0, e_sd = 0;
+        uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0;
         if ((uint32_t)lane < nent) {
             const uint32_t c = ent_c, i = ent_i;
             if (rc.on(c)) {
@@ -1379,7 +1395,6 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
                 if (sd >= COLD(total_kmers)) sd = (uint32_t)guard_idx(cx, G_KMER2, 0x80000000u | pos | (seg << 16) | (c << 24) | (mode << 26), 0, r);
                 if (m != 0 && m <= cx.max_kmer_num) {
                     e_m = m;
-                    e_sd = sd;
                     e_off = cx.kmer_off[sd];
                     e_nfwd = cx.kmer_nfwd[sd];
                     e_h = pos;
@@ -1428,22 +1443,6 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
         const uint32_t T = rdlane(inc, (int)nent - 1);
         PH(PH_MODE);
 
-        if constexpr (!GAP && !HEAVY) {
-            // pass 1 of a two-pass launch: a read that meets a long list is set aside for the HEAVY kernel (nothing of it has left the wave yet)
-            if (COLDP(uint32_t, defer_keys) != nullptr) {
-                const uint64_t hv = ballot((uint32_t)lane < nent && e_m >= COLD(heavy_m));
-                if (hv) {
-                    const uint32_t key = rdlane(e_sd, __ffsll((unsigned long long)hv) - 1);
-                    if (lane0(lane)) {
-                        const uint32_t at = atomicAdd(COLDP(unsigned int, defer_count), 1u);
-                        if (at < cx.n) { COLDP(uint32_t, defer_keys)[at] = key; COLDP(uint32_t, defer_reads)[at] = r; }
-                    }
-                    res.status = BASAL_READ_DEFERRED;
-                    if (lane0(lane)) L.res[chunk_slot] = res;
-                    return;
-                }
-            }
-        }
         if constexpr (HEAVY) {
             done = heavy_mode<NWT, NEWRULE>(cx, L, st, log, rc, mode, inc, e_m, nent, T, r, lane PH_ARG);
         } else {
@@ -1851,13 +1850,12 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
         // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
         if (ballot(1) != ~0ULL) { guard_idx(cx, G_WATCHDOG, 0x20000u | (uint32_t)__popcll(ballot(1)), 0, iter); break; }
         uint32_t base = 0;
-        const uint32_t take = COLD(work_chunk);
-        if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)take);
+        if (lane0(lane)) base = atomicAdd(cx.work_counter, (unsigned int)WORK_CHUNK);
         base = rfl(base);
         PH(PH_QUEUE);
         if (base >= n_items) break;
         if (iter > n_items) { guard_idx(cx, G_WATCHDOG, iter, 0, base); break; }
-        const uint32_t end = base + take < n_items ? base + take : n_items;
+        const uint32_t end = base + WORK_CHUNK < n_items ? base + WORK_CHUNK : n_items;
         // The chunk's descriptors come in with one load, and each read's bytes are requested while the read before it
         // is being aligned, so a read starts on data that is already in registers (2 memory round trips per chunk
         // instead of 2 per read).
@@ -1987,8 +1985,6 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_names); hipFree(c->d_name_off);
-    for (int b = 0; b < 2; b++) { hipFree(c->d_defer_keys[b]); hipFree(c->d_defer_reads[b]); }
-    hipFree(c->d_defer_count); hipFree(c->d_sort_tmp);
     hipFree(c->d_pe_pairs); hipFree(c->d_pe_recs); hipFree(c->d_pe_work); hipFree(c->d_pe_misc);
     hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -2168,63 +2164,30 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     const bool hv = c->heavy && !gp;
     {
         const char *e = getenv("BASAL_HEAVY_M");  // (tests: 1 sends every list through the long-list loop)
-        cx.heavy_m = e ? (uint32_t)atoi(e) : 512u;
+        cx.heavy_m = e ? (uint32_t)atoi(e) : 128u;
         if (cx.heavy_m < 1) cx.heavy_m = 1;
     }
     kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv) : nwt == 8 ? pick_kernel<8>(nr, gp, hv) : pick_kernel<16>(nr, gp, hv);
     HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
     cx.guard = counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
-    cx.work_chunk = WORK_CHUNK;
     const char *env = getenv("BASAL_BLOCKS_PER_CU");
-    auto grid_for = [&](bool heavy_k, uint32_t chunk) {
-        uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, heavy_k);
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu > 8) per_cu = 8;
-        uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;
-        c->last_grid = grid;
-        const uint32_t need = (n + 4 * chunk - 1) / (4 * chunk);
-        return grid > need ? need : grid;
-    };
-    // Two passes (heavy cores, plain launches): the standard kernel first, which sets the reads that meet a long list aside; those, sorted by
-    // the k-mer of that list, then go through the HEAVY kernel -- reads that stream the same lists run side by side and find them in L2 / the
-    // Infinity Cache instead of each pulling megabytes from HBM. BASAL_TWO_PASS=0: one pass of the HEAVY kernel over everything.
-    static const bool two_pass_env = !(getenv("BASAL_TWO_PASS") && atoi(getenv("BASAL_TWO_PASS")) == 0);
-    const bool two_pass = hv && !ex && two_pass_env;
-    if (two_pass) {
-        if ((rc = basal_defer_reserve(c, n))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_defer_count, 0, sizeof(unsigned int), s));
-        HIP_TRY(hipMemsetAsync(c->d_defer_keys[0], 0x04, (size_t)n * 4, s));  // filler key 0x04040404 >= 2^26: behind every k-mer id
-        cx.defer_keys = c->d_defer_keys[0]; cx.defer_reads = c->d_defer_reads[0]; cx.defer_count = c->d_defer_count;
-        k = nwt == 4 ? pick_kernel<4>(nr, gp, false) : nwt == 8 ? pick_kernel<8>(nr, gp, false) : pick_kernel<16>(nr, gp, false);
-    }
-    uint32_t grid = grid_for(hv && !two_pass, WORK_CHUNK);
+    uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, hv);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;
+    c->last_grid = grid;
+    uint32_t need = (n + 4 * WORK_CHUNK - 1) / (4 * WORK_CHUNK);
+    if (grid > need) grid = need;
     if (c->timing && !ex) HIP_TRY(hipEventRecord(c->ev0, s));
     static const bool dbg = getenv("BASAL_DEBUG") != nullptr;
     if (dbg) {
         HIP_TRY(hipStreamSynchronize(s));
-        fprintf(stderr, "[basal debug] launching align kernel NWT=%d newrule=%d gap=%d heavy=%d two_pass=%d grid=%u n=%u nstale=%u max_kmer_num=%u nlocs=%llu\n", nwt, (int)nr,
-                (int)gp, (int)hv, (int)two_pass, grid, n, cx.nstale, cx.max_kmer_num, (unsigned long long)c->nlocs);
+        fprintf(stderr, "[basal debug] launching align kernel NWT=%d newrule=%d gap=%d heavy=%d grid=%u n=%u nstale=%u max_kmer_num=%u nlocs=%llu\n", nwt, (int)nr,
+                (int)gp, (int)hv, grid, n, cx.nstale, cx.max_kmer_num, (unsigned long long)c->nlocs);
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, cx);
     HIP_TRY(hipGetLastError());
-    if (two_pass) {
-        if ((rc = basal_defer_sort(c, n, s))) return rc;
-        HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));
-        DevCtx c2 = cx;
-        c2.defer_keys = c2.defer_reads = nullptr; c2.defer_count = nullptr;
-        c2.order = c->d_defer_reads[1];
-        c2.n_ptr = c->d_defer_count;
-        {
-            const char *e = getenv("BASAL_HEAVY_CHUNK");  // heavy reads run for a long time each: few per queue ticket, so that the launch ends evenly
-            c2.work_chunk = e ? (uint32_t)atoi(e) : 2u;
-            if (c2.work_chunk < 1 || c2.work_chunk > WORK_CHUNK) c2.work_chunk = WORK_CHUNK;
-        }
-        kernel_fn k2 = nwt == 4 ? pick_kernel<4>(nr, gp, true) : nwt == 8 ? pick_kernel<8>(nr, gp, true) : pick_kernel<16>(nr, gp, true);
-        const uint32_t grid2 = grid_for(true, c2.work_chunk);
-        hipLaunchKernelGGL(k2, dim3(grid2), dim3(256), 0, s, c2);
-        HIP_TRY(hipGetLastError());
-    }
     if (dbg) {
         HIP_TRY(hipStreamSynchronize(s));
         fprintf(stderr, "[basal debug] align kernel finished\n");

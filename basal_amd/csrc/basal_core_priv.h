@@ -41,12 +41,6 @@ struct basal_core {
     basal_pe_rec *d_pe_recs = nullptr; size_t cap_pe_recs = 0;
     basal_hit *d_pe_work = nullptr; size_t cap_pe_work = 0;
     unsigned long long *d_pe_misc = nullptr;  // [0] records used, then nine 32-bit statistics
-    // two-pass launches (heavy cores): the reads pass 1 sets aside, as (k-mer, read number) pairs, double-buffered for the radix sort
-    uint32_t *d_defer_keys[2] = {nullptr, nullptr}, *d_defer_reads[2] = {nullptr, nullptr};
-    unsigned int *d_defer_count = nullptr;
-    size_t cap_defer = 0;
-    void *d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
     // contig names for the device-side SAM writer (basal_core_set_contig_names)
     char *d_names = nullptr;
     uint32_t *d_name_off = nullptr;
@@ -73,6 +67,3 @@ int basal_ensure_launch_geometry(basal_core *c);  // sizes c->grid (largest grid
 int basal_report_guard(const unsigned int *guard);  // BASAL_OK, or BASAL_EDEVICE + message if the kernel's bounds ledger is not clean
 
 int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys);
-// basal_index.hip: (re)allocates the deferral buffers for n reads; sorts the n (key, read) pairs of buffer 0 into buffer 1 by key, on stream s
-int basal_defer_reserve(basal_core *c, size_t n);
-int basal_defer_sort(basal_core *c, size_t n, hipStream_t s);  // basal_index.hip: fills d_flank_a/d_flank_b from the staged reference + index

@@ -202,33 +202,6 @@ int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys) {
     return BASAL_OK;
 }
 
-// ---- two-pass launches: the (k-mer, read number) pairs of the reads pass 1 set aside, sorted by k-mer for pass 2 ----------------------------
-static const int kDeferKeyBits = 27;  // k-mer ids are < 3^16 < 2^26; pairs never written keep the filler key 2^26 and sort behind every real one
-int basal_defer_reserve(basal_core *c, size_t n) {
-    if (n <= c->cap_defer) return BASAL_OK;
-    for (int b = 0; b < 2; b++) { hipFree(c->d_defer_keys[b]); hipFree(c->d_defer_reads[b]); c->d_defer_keys[b] = c->d_defer_reads[b] = nullptr; }
-    hipFree(c->d_sort_tmp);
-    c->d_sort_tmp = nullptr;
-    c->cap_defer = 0;
-    const size_t cap = n + n / 4 + 1024;
-    for (int b = 0; b < 2; b++) {
-        HIP_TRYI(hipMalloc(&c->d_defer_keys[b], cap * 4));
-        HIP_TRYI(hipMalloc(&c->d_defer_reads[b], cap * 4));
-    }
-    if (!c->d_defer_count) HIP_TRYI(hipMalloc(&c->d_defer_count, sizeof(unsigned int)));
-    size_t tb = 0;
-    HIP_TRYI(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, c->d_defer_keys[0], c->d_defer_keys[1], c->d_defer_reads[0], c->d_defer_reads[1], cap, 0, kDeferKeyBits));
-    HIP_TRYI(hipMalloc(&c->d_sort_tmp, tb + 256));
-    c->sort_tmp_bytes = tb + 256;
-    c->cap_defer = cap;
-    return BASAL_OK;
-}
-int basal_defer_sort(basal_core *c, size_t n, hipStream_t s) {
-    size_t tb = c->sort_tmp_bytes;
-    HIP_TRYI(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tb, c->d_defer_keys[0], c->d_defer_keys[1], c->d_defer_reads[0], c->d_defer_reads[1], n, 0, kDeferKeyBits, s));
-    return BASAL_OK;
-}
-
 extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, uint64_t nblocks, uint32_t *max_kmer_num_out) {
     if (!c || (!blocks && nblocks)) { set_error("build_index: null argument"); return BASAL_EINVAL; }
     if (!c->have_ref) { set_error("build_index: stage the reference first (basal_core_set_reference)"); return BASAL_ESTATE; }

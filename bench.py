@@ -186,7 +186,7 @@ def bench_pairs(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     paired = st[0] / (npairs * args.steps)
-    out = {"metric": "Mreads/s aligned (100 bp SE, -M C:T, hg38) at 1/2/4/8 GPUs; SAM bit-identical", "value": 2 * npairs * args.steps / dt / 1e6, "unit": "Mreads/s",
+    out = {"metric": "Mpairs/s aligned and paired (150 bp PE, -M A:G, transcriptome stand-in), host buffers to host records", "value": npairs * args.steps / dt / 1e6, "unit": "Mpairs/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u64", "data": "synthetic",
            "config": {"workload": "config 3: %d k synthetic 150 bp read pairs per step, -M A:G -S 1, transcriptome stand-in (%d contigs, %.0f Mbp), mates aligned with every mode + "
@@ -216,10 +216,14 @@ def main():
                          "BID-seq pipeline flags -n 1 -g 3")
     ap.add_argument("--rule", default=None, help="ad hoc: another -M rule with config 2's kind of reads")
     ap.add_argument("--gap", type=int, default=None)
-    ap.add_argument("--genome", default="uniform", choices=["uniform", "realistic"],
-                    help="uniform: random bases + one planted 300-base family (the bench line's stand-in); realistic: a repeat landscape shaped like hg38's "
-                         "(Alu / L1 / MIR / L2 / LTR / DNA families + satellites, ~45 %% of the genome): the over-represented-k-mer cut-off then lands where "
-                         "seeds from repeats keep tens of thousands of candidates, as on the real genome")
+    ap.add_argument("--genome", default="realistic", choices=["uniform", "realistic"],
+                    help="realistic (the bench line's stand-in for hg38): a repeat landscape shaped like hg38's (Alu / L1 / MIR / L2 / LTR / DNA families + "
+                         "satellites, ~45 %% of the genome): the over-represented-k-mer cut-off then lands where seeds from repeats keep tens of thousands of "
+                         "candidates, as on the real genome; uniform: random bases + one planted 300-base family (rounds 1-2's stand-in, 9 x easier; the "
+                         "default run reports it as config.uniform_genome_mreads_per_s)")
+    ap.add_argument("--fasta", default=os.environ.get("BASAL_HG38_FASTA"),
+                    help="align against this FASTA (e.g. hg38) instead of a synthetic genome: loaded by the product's loader (basal_host_ref_load), reads are "
+                         "sampled from it; default: $BASAL_HG38_FASTA if set")
     ap.add_argument("--contigs", type=int, default=100_000, help="config 3: contigs of the transcriptome stand-in (<= 64: the 24-contig genome-shaped stand-in instead)")
     ap.add_argument("--read-len", type=int, default=100, help="read length (the headline workload is 100; 150/300 exercise the 256/480-base kernels)")
     args = ap.parse_args()
@@ -275,8 +279,12 @@ def main():
 
     # ---- reference + index, staged once -----------------------------------------------------
     t0 = time.time()
-    G = synth_gpu.make_genome(params, dev, scale=args.genome_scale, seed=1, repeat_copies=int(os.environ.get("BASAL_BENCH_REPEAT_COPIES", "40000")),
-                              realistic=args.genome == "realistic")
+    if args.fasta:
+        G = synth_gpu.genome_from_reference(params, B.Reference(params, fasta_path=args.fasta), dev)
+        args.genome = "fasta"
+    else:
+        G = synth_gpu.make_genome(params, dev, scale=args.genome_scale, seed=1, repeat_copies=int(os.environ.get("BASAL_BENCH_REPEAT_COPIES", "40000")),
+                                  realistic=args.genome == "realistic")
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     words = [w.cpu().numpy().view(np.uint64) for w in G.words]
@@ -290,7 +298,7 @@ def main():
     bc._check(L.basal_core_build_index(core.h, blocks.ctypes.data, len(blocks), C.byref(mk)), "build_index")
     t_index = time.time() - t0
     total_bp = int(sizes.sum())
-    log("genome %.3f Gbp in %d contigs generated in %.1f s; reference staged + seed index built on the GPU in %.1f s (cut-off %d)"
+    log(("genome %.3f Gbp in %d contigs " + ("loaded from " + args.fasta if args.fasta else "generated") + " in %.1f s; reference staged + seed index built on the GPU in %.1f s (cut-off %d)")
         % (total_bp / 1e9, len(sizes), t_gen, t_index, mk.value))
 
     # ---- reads resident in HBM -----------------------------------------------------------------
@@ -423,8 +431,8 @@ def main():
         "value": reads_timed / dt / 1e6, "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": ("config %s: %d M synthetic %d bp SE reads per GPU (%d per step), -M %s -g %d -S 1%s, hg38-sized synthetic genome "
-                                "(%.2f Gbp, %d contigs, N gaps, " + ("hg38-like repeat landscape: ~45 %% repeats" if args.genome == "realistic" else "planted repeats") + "), reference + seed index resident in HBM, reads resident in HBM, every step's hit "
+        "config": {"workload": ("config %s: %d M synthetic %d bp SE reads per GPU (%d per step), -M %s -g %d -S 1%s, " + ("the genome in " + os.path.basename(args.fasta) + " " if args.fasta else "hg38-sized synthetic genome ") +
+                                "(%.2f Gbp, %d contigs, N gaps, " + ("hg38-like repeat landscape: ~45 %% repeats" if args.genome == "realistic" else "as loaded" if args.fasta else "uniform bases + one planted repeat family") + "), reference + seed index resident in HBM, reads resident in HBM, every step's hit "
                                 "records copied to page-locked host memory inside the timed region")
                                % (args.config, args.batch * args.steps // 1_000_000, args.read_len, args.batch, args.rule, args.gap, (" " + " ".join(p_extra)) if p_extra else "",
                                   total_bp / 1e9, len(sizes)),
@@ -433,9 +441,9 @@ def main():
                    "index_build_s": round(t_index, 2)},
     }
 
-    headline = args.config == "2" and not adhoc and args.read_len == 100 and args.genome_scale == 1.0 and args.genome == "uniform"
-    kernel_name = "align_kernel<%d,%s,%s>" % (4 if read_len <= 128 else 8 if read_len <= 256 else 16, "true" if params.c.new_rule else "false",
-                                              "true" if args.gap > 0 else "false")
+    headline = args.config == "2" and not adhoc and args.read_len == 100 and args.genome_scale == 1.0 and args.genome == "realistic"
+    kernel_name = "align_kernel<%d,%s,%s,%s>" % (4 if read_len <= 128 else 8 if read_len <= 256 else 16, "true" if params.c.new_rule else "false",
+                                                 "true" if args.gap > 0 else "false", "HEAVY" if (mk.value >= 32768 and args.gap == 0 and os.environ.get("BASAL_HEAVY", "1") != "0") else "false")
     # ---- cpu_baseline + parity on a bounded sample (rank 0, N=1 only) + roofline ------------------
     cpu = None
     roof = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
@@ -483,8 +491,9 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):  # a per-launch, per-GPU figure; the committed passes cover the headline workload, configs 4 and 5p and the realistic genome
         t = json.load(open(tj))
-        key = None if headline else ("realistic" if (args.config == "2" and args.genome == "realistic" and args.read_len == 100 and not args.rule and args.gap is None)
-                                     else {"4": "config4", "5p": "config5p"}.get(args.config) if (args.genome == "uniform" and args.read_len == 100 and not args.rule and args.gap is None) else "-")
+        plain = args.read_len == 100 and not adhoc and args.genome_scale == 1.0
+        key = None if headline else ({"2": "uniform", "4": "config4", "5": "config5", "5p": "config5p"}.get(args.config) if (plain and args.genome == "uniform") else
+                                     {"4": "config4_realistic", "5p": "config5p_realistic"}.get(args.config, "-") if (plain and args.genome == "realistic") else "-")
         t = t if key is None else t.get("other_workloads", {}).get(key)
         if t:
             roof["traffic"] = t["hbm_bytes_per_read"] * args.batch
@@ -537,6 +546,20 @@ def main():
             out["config"]["cpu_port"] = cpu
             cpu = ref_cpu
     out["cpu_baseline"] = cpu
+    # The default line also carries rounds 1-2's headline workload, the uniform stand-in genome, measured by the same script in a child process
+    # (its own genome, index and oracle-checked sample; this process's core stays resident meanwhile: 288 GB hold both).
+    if rank == 0 and world == 1 and headline and cpu is not None and not os.environ.get("BASAL_BENCH_NO_UNIFORM"):
+        import subprocess
+        env = dict(os.environ, BASAL_BENCH_NO_H2H="1", BASAL_BENCH_NO_UNIFORM="1")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--genome", "uniform", "--steps", "5", "--warmup", "1", "--cpu-sample", "200000", "--ref-sample", "0"],
+                           capture_output=True, text=True, env=env)
+        try:
+            u = json.loads(r.stdout.strip().splitlines()[-1])
+            out["config"]["uniform_genome_mreads_per_s"] = round(u["value"], 1)
+            out["config"]["uniform_genome_roofline_frac"] = round(u["roofline"]["frac"], 3)
+            out["config"]["uniform_genome_note"] = "config 2 on the uniform stand-in genome (rounds 1-2's bench line): 5 steps of 10 M reads, 200 000-read sample identical to the oracle"
+        except Exception as e:
+            log("uniform-genome leg failed: %r %s" % (e, r.stderr[-300:]))
     if rank == 0:
         print(json.dumps(out))
     if dist_on:

@@ -163,6 +163,41 @@ def make_genome(params, device, scale=1.0, seed=1, n_contigs=24, repeat_copies=4
     return G
 
 
+def genome_from_reference(params, ref, device):
+    """A Genome (what make_reads / bench.py need) from a reference the PRODUCT's loader read (basal_amd.Reference on a FASTA, e.g. hg38):
+    packed words of both strands as loaded, per-contig base ids decoded from the forward strand for the read sampler, N runs from the gaps
+    between the loader's blocks (refbase.cpp:103-128: maximal runs without N of >= 16 bases)."""
+    G = Genome()
+    G.names = ref.names()
+    G.sizes = [int(x) for x in ref.sizes()]
+    G.anchors = np.array(ref.anchors(), dtype=np.uint32, copy=True)  # (copies: the arrays the loader hands out live as long as `ref` does)
+    G.rc_offsets = np.array(ref.rc_offsets(), dtype=np.uint32, copy=True)
+    G.blocks = np.array(ref.blocks(), dtype=np.uint32, copy=True)
+    G.words = [torch.from_numpy(np.ascontiguousarray(ref.words(s)).view(np.int64).copy()).to(device) for s in (0, 1)]
+    al, _ = _codes(params)
+    inv = torch.zeros(4, dtype=torch.uint8)
+    for base, code in enumerate(al):
+        inv[code] = base
+    inv = inv.to(device)
+    sh = torch.arange(31, -1, -1, device=device, dtype=torch.int64) * 2
+    G.ids, G.nmask_runs = [], []
+    blocks = G.blocks.reshape(-1, 3)
+    for ci, size in enumerate(G.sizes):
+        w0 = int(G.anchors[ci]) // 32
+        nw = (size + 31) // 32
+        codes = ((G.words[0][w0:w0 + nw, None] >> sh[None, :]) & 3).reshape(-1)[:size]
+        G.ids.append(inv[codes])
+        runs, prev = [], 0
+        for _, b, e in sorted((int(x[0]), int(x[1]), int(x[2])) for x in blocks[blocks[:, 0] == 2 * ci]):
+            if b > prev:
+                runs.append((prev, b))
+            prev = e
+        if prev < size:
+            runs.append((prev, size))
+        G.nmask_runs.append(runs)
+    return G
+
+
 def make_transcriptome(params, device, n_contigs=100_000, seed=1, median=1200, sigma=0.8, lo=300, hi=20_000):
     """A transcriptome-shaped reference for BASELINE.json config 3 ("transcriptome stand-in with <= 131 071
     contigs"): n_contigs sequences of log-normal length (median 1.2 kb, clipped to lo..hi), uniform ACGT, no N's -- about 0.15 Gbp at
