@@ -17,23 +17,44 @@ sys.path.insert(0, os.path.join(H.ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 CONFIGS = {
-    # name: (rule, flags, read_len, n_reads, p_conv, sub_rate)
+    # name: (rule, flags, read_len, n_reads, p_conv, sub_rate[, make_reads overrides: the SURVEY 8d shapes bench.py also uses][, genome overrides])
     "c2_ct_g0": ("C:T", ["-M", "C:T", "-S", "1"], 100, 200_000, 0.95, 0.01),
     "c3_ag_150": ("A:G", ["-M", "A:G", "-S", "1", "-n", "1"], 150, 60_000, 0.9, 0.01),
     "c4_acgt_g2": ("A:CGT", ["-M", "A:CGT", "-S", "1", "-g", "2"], 100, 60_000, 0.3, 0.01),
     "c5_tdel": ("T:-", ["-M", "T:-", "-S", "1"], 100, 100_000, 0.0, 0.01),
     "c5_tdel_pipeline": ("T:-", ["-M", "T:-", "-S", "1", "-n", "1", "-g", "3"], 100, 40_000, 0.0, 0.01),
+    # SURVEY 8d's read shapes: config 4 = each A to one of C/G/T with p 0.3 + 1 % of the reads with a 1-2 base indel; config 5 = 30 % of the reads with one T deleted
+    "c4_acgt_g2_8d": ("A:CGT", ["-M", "A:CGT", "-S", "1", "-g", "2"], 100, 60_000, 0.3, 0.01, dict(conv_from=0, conv_to=[1, 2, 3], p_conv=0.3, indel_frac=0.01, indel_max=2)),
+    "c5_tdel_8d": ("T:-", ["-M", "T:-", "-S", "1"], 100, 100_000, 0.0, 0.01, dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80)),
+    "c5_tdel_pipeline_8d": ("T:-", ["-M", "T:-", "-S", "1", "-n", "1", "-g", "3"], 100, 40_000, 0.0, 0.01,
+                            dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80)),
+    # the 256- and 480-base GAP kernels (<8,*,true>, <16,*,true>) at scale
+    "ct_150_g2": ("C:T", ["-M", "C:T", "-S", "1", "-g", "2"], 150, 40_000, 0.95, 0.01, dict(indel_frac=0.05, indel_max=2)),
+    "ct_300_g1": ("C:T", ["-M", "C:T", "-S", "1", "-g", "1"], 300, 20_000, 0.95, 0.01, dict(indel_frac=0.05, indel_max=1)),
+    # the hg38-like repeat landscape (long streams): configs 4 and 5p on it, and config 2 on a genome large enough for the index's cut-off to
+    # pass 32 768 by itself, which is what selects the HEAVY kernels (no environment override here)
+    "c4_realistic": ("A:CGT", ["-M", "A:CGT", "-S", "1", "-g", "2"], 100, 30_000, 0.3, 0.01, dict(conv_from=0, conv_to=[1, 2, 3], p_conv=0.3, indel_frac=0.01, indel_max=2),
+                     dict(realistic=True, scale=0.05)),
+    "c5p_realistic": ("T:-", ["-M", "T:-", "-S", "1", "-n", "1", "-g", "3"], 100, 20_000, 0.0, 0.01, dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80),
+                      dict(realistic=True, scale=0.05)),
+    "c2_realistic_heavy": ("C:T", ["-M", "C:T", "-S", "1"], 100, 200_000, 0.95, 0.01, None, dict(realistic=True, scale=0.4, min_cutoff=32768)),
 }
+RELAXED = ("c4_acgt_g2", "c4_acgt_g2_8d", "c4_realistic")  # A:CGT: see the comment in the test
 
 
 def setup(name, scale=0.02, n_reads=None):
     import torch
     import synth_gpu
-    rule, flags, rl, n, pconv, sub = CONFIGS[name]
+    cfg = CONFIGS[name]
+    rule, flags, rl, n, pconv, sub = cfg[:6]
+    read_over = cfg[6] if len(cfg) > 6 and cfg[6] else {}
+    gen = dict(cfg[7]) if len(cfg) > 7 else {}
+    scale = gen.pop("scale", scale)
+    min_cutoff = gen.pop("min_cutoff", 0)
     n = n_reads or n
     dev = torch.device("cuda", 0)
     p = B.Params(rule, flags)
-    G = synth_gpu.make_genome(p, dev, scale=scale, seed=3)
+    G = synth_gpu.make_genome(p, dev, scale=scale, seed=3, **gen)
     words = [w.cpu().numpy().view(np.uint64) for w in G.words]
     sizes = np.array(G.sizes, dtype=np.uint32)
     core = B.Core(p, 0)
@@ -43,10 +64,13 @@ def setup(name, scale=0.02, n_reads=None):
     mk = C.c_uint32()
     blocks = np.ascontiguousarray(G.blocks)
     bc._check(L.basal_core_build_index(core.h, blocks.ctypes.data, len(blocks), C.byref(mk)), "build_index")
+    assert mk.value >= min_cutoff, "the over-represented-k-mer cut-off of this genome is %d: too low to select the HEAVY kernels" % mk.value
     frm = "ACGT".index(rule[0])
     tos = [t for t in rule[2:] if t in "ACGT"]
     to = "ACGT".index(tos[0]) if tos else frm
-    bases, ci, start, rev = synth_gpu.make_reads(G, n, dev, read_len=rl, seed=11, conv_from=frm, conv_to=to, p_conv=pconv if tos else 0.0, sub_rate=sub)
+    kw = dict(conv_from=frm, conv_to=to, p_conv=pconv if tos else 0.0, sub_rate=sub)
+    kw.update(read_over)
+    bases, ci, start, rev = synth_gpu.make_reads(G, n, dev, read_len=rl, seed=11, **kw)
     hb = bases.cpu().numpy()
     seq = C.create_string_buffer(b"A" * rl, rl + 2)
     qual = C.create_string_buffer(b"I" * rl, rl + 2)
@@ -56,7 +80,11 @@ def setup(name, scale=0.02, n_reads=None):
     descs["seq_off"] = np.arange(n, dtype=np.uint64) * rl
     descs["index"] = np.arange(n, dtype=np.uint32)
     descs["len"], descs["max_snp"], descs["stale_idx"] = rl, ms.value, B.STALE_NONE
-    return p, flags, G, words, sizes, core, hb, descs, (ci.cpu().numpy(), start.cpu().numpy(), rev.cpu().numpy())
+    # make_reads cuts a read with an indel out of a window pad bases longer, and a reverse-strand read out of that window's reverse complement:
+    # its leftmost reference base is then pad bases behind the window's start
+    pad = (kw.get("indel_max", 2) + 1) if (kw.get("indel_frac", 0) > 0 or kw.get("del_frac", 0) > 0) else 0
+    rev_np = rev.cpu().numpy()
+    return p, flags, G, words, sizes, core, hb, descs, (ci.cpu().numpy(), start.cpu().numpy() + pad * rev_np.astype(np.int64), rev_np)
 
 
 def run(core, hb, descs, split=None):
@@ -87,14 +115,19 @@ def test_config_matches_oracle_on_sample_and_properties(name):
     # 2. planted truth: a uniquely aligned ungapped read sits where it was sampled from
     # A:CGT seeds only tolerate the conversion to the base coded 11 (A<->T), so reads whose A's became C
     # lose seeds and a share of them cannot be placed -- in the reference too (the oracle sample above agrees)
-    assert (res["best_level"] != 0xFF).mean() > (0.75 if name == "c4_acgt_g2" else 0.95)
+    realistic = "realistic" in name  # reads from repeats are legitimately multiple there
+    dels = name.startswith("c5") and name.endswith("8d") and "-g" not in flags  # a read with a deleted base cannot be placed without -g
+    assert (res["best_level"] != 0xFF).mean() > (0.6 if name in RELAXED or dels else 0.9 if realistic else 0.95)
     uniq_any = (res["best_level"] != 0xFF) & (res["n_hit"].astype(np.uint32) + res["n_chit"] == 1)
     # with -g the reference stores an ungapped and a gapped placement of the same locus as two hits, so many
-    # reads count as "multiple" there; without -g nearly every read of this random genome is unique
-    assert uniq_any.mean() > (0.5 if "-g" in flags else 0.95)
+    # reads count as "multiple" there; without -g nearly every read of the uniform genome is unique
+    assert uniq_any.mean() > (0.4 if "-g" in flags or dels else 0.8 if realistic else 0.95)
     uniq = uniq_any & (res["best"]["gap_size"] == 0)
     ok = (res["best"]["chr"] >> 1 == ci) & (res["best"]["loc"] == start)
-    assert ok[uniq].mean() > 0.995
+    if "8d" not in name and "realistic" not in name and not name.startswith("ct_"):  # (a read cut around an indel starts where its first base came from, not at the window's start)
+        assert ok[uniq].mean() > 0.995
+    else:
+        assert ok[uniq].mean() > 0.9
     # strand bookkeeping: reverse-strand reads of a directional library land on the RC reference strand
     if "-n" not in flags:
         assert ((res["best"]["chr"] & 1) == rev)[uniq & ok].all()
@@ -103,6 +136,21 @@ def test_config_matches_oracle_on_sample_and_properties(name):
     assert res.tobytes() == res2.tobytes()
     # 4. idempotence
     assert run(core, hb, descs).tobytes() == res.tobytes()
+
+
+def test_gap_bounds_check_build_at_scale():
+    """The `chk` twin of the library (every candidate of the GAP kernels scored exactly; the launch fails if the stream's bounds would have
+    dropped an accepted one) on config 4's SURVEY 8d reads at scale, results = the oracle's on the sample.  (A library is loaded once per
+    process, hence the child.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "basal_amd", "csrc"), "chk"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, BASAL_LIB=os.path.join(root, "basal_amd", "lib", "libbasal_amd_chk.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_config_matches_oracle_on_sample_and_properties and (c4_acgt_g2_8d or ct_150_g2)"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "2 passed" in r.stdout, r.stdout[-500:]
 
 
 def test_read_order_independence():
