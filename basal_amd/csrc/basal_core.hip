@@ -2261,6 +2261,31 @@ extern "C" int basal_core_align_batch_device(basal_core_t *c, const void *d_base
                         carry ? carry : zero_carry, (hipStream_t)hip_stream);
 }
 
+// What every host-buffer entry point checks of a batch before anything is queued (one helper: basal_core_align_batch, _align_pairs_batch
+// and basal_multi_align_batch must refuse the same descriptors). who: the entry point's name for the message. max_len: the longest read.
+int basal_validate_batch(const basal_params &P, const basal_read *reads, uint32_t n, uint64_t nbases, const basal_stale *stales, uint32_t nstale, const char *who,
+                         uint32_t *max_len_out) {
+    uint32_t max_len = 0;
+    const uint32_t K = P.seed_size, I = P.index_interval;
+    auto bad = [&](const char *what) { g_err = std::string(who) + ": " + what; return BASAL_EINVAL; };
+    // basal_read.seq_off is 32 bits: a batch whose bases do not fit would wrap the offsets and align reads against the wrong bytes
+    if (nbases > 0xFFFFFFFFull) return bad("more than 4 GiB of bases in one batch (basal_read.seq_off is 32-bit); split the batch");
+    for (uint32_t i = 0; i < n; i++) {
+        const basal_read &r = reads[i];
+        if (r.len == 0) continue;
+        if (r.len > BASAL_MAXREADLEN || (uint64_t)r.seq_off + r.len > nbases) return bad("read descriptor out of range");
+        if (r.max_snp > BASAL_MAXSNPS) return bad("max_snp > 15");
+        if (r.stale_idx != BASAL_STALE_NONE) {
+            if (!stales || r.stale_idx >= nstale) return bad("stale_idx outside the stale table");
+            const uint32_t src = stales[r.stale_idx].src;
+            if (src != BASAL_STALE_CARRY && (src >= i || reads[src].len < K + I - 1)) return bad("basal_stale.src must name an earlier aligned read");
+        }
+        if (r.len > max_len) max_len = r.len;
+    }
+    *max_len_out = max_len;
+    return BASAL_OK;
+}
+
 template <typename T>
 static int grow(T *&p, size_t &cap, size_t need) {
     if (need <= cap) return BASAL_OK;
@@ -2280,22 +2305,8 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     HIP_TRY(hipSetDevice(c->device));
     if (stream_used) *stream_used = 0;
     if (n == 0) return BASAL_OK;
-    // basal_read.seq_off is 32 bits: a batch whose bases do not fit would wrap the offsets and align reads against the wrong bytes
-    if (nbases > 0xFFFFFFFFull) { g_err = "align_batch: more than 4 GiB of bases in one batch (basal_read.seq_off is 32-bit); split the batch"; return BASAL_EINVAL; }
     uint32_t max_len = 0;
-    const uint32_t K = c->p.seed_size, I = c->p.index_interval;
-    for (uint32_t i = 0; i < n; i++) {
-        const basal_read &r = reads[i];
-        if (r.len == 0) continue;
-        if (r.len > BASAL_MAXREADLEN || (uint64_t)r.seq_off + r.len > nbases) { g_err = "align_batch: read descriptor out of range"; return BASAL_EINVAL; }
-        if (r.max_snp > BASAL_MAXSNPS) { g_err = "align_batch: max_snp > 15"; return BASAL_EINVAL; }
-        if (r.stale_idx != BASAL_STALE_NONE) {
-            if (!stales || r.stale_idx >= nstale) { g_err = "align_batch: stale_idx outside the stale table"; return BASAL_EINVAL; }
-            uint32_t src = stales[r.stale_idx].src;
-            if (src != BASAL_STALE_CARRY && (src >= i || reads[src].len < K + I - 1)) { g_err = "align_batch: basal_stale.src must name an earlier aligned read"; return BASAL_EINVAL; }
-        }
-        if (r.len > max_len) max_len = r.len;
-    }
+    if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_batch", &max_len)) return vrc;
     int rc;
     size_t cap_res = c->cap_reads;
     if ((rc = grow(c->d_bases, c->cap_bases, nbases + 64))) return rc;
@@ -2362,24 +2373,11 @@ extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *base
     const uint32_t n = 2 * npairs;
     if (!c || (npairs && (!bases || !reads || !pairs_out || !recs_out || !recs_used))) { g_err = "align_pairs_batch: null argument"; return BASAL_EINVAL; }
     if (npairs > 0x7FFFFFFFu / 2) { g_err = "align_pairs_batch: too many pairs in one batch"; return BASAL_EINVAL; }
-    if (nbases > 0xFFFFFFFFull) { g_err = "align_pairs_batch: more than 4 GiB of bases in one batch (basal_read.seq_off is 32-bit); split the batch"; return BASAL_EINVAL; }
     *recs_used = 0;
     if (n == 0) return BASAL_OK;
     HIP_TRY(hipSetDevice(c->device));
     uint32_t max_len = 0;
-    const uint32_t K = c->p.seed_size, I = c->p.index_interval;
-    for (uint32_t i = 0; i < n; i++) {
-        const basal_read &r = reads[i];
-        if (r.len == 0) continue;
-        if (r.len > BASAL_MAXREADLEN || (uint64_t)r.seq_off + r.len > nbases) { g_err = "align_pairs_batch: read descriptor out of range"; return BASAL_EINVAL; }
-        if (r.max_snp > BASAL_MAXSNPS) { g_err = "align_pairs_batch: max_snp > 15"; return BASAL_EINVAL; }
-        if (r.stale_idx != BASAL_STALE_NONE) {
-            if (!stales || r.stale_idx >= nstale) { g_err = "align_pairs_batch: stale_idx outside the stale table"; return BASAL_EINVAL; }
-            const uint32_t src = stales[r.stale_idx].src;
-            if (src != BASAL_STALE_CARRY && (src >= i || reads[src].len < K + I - 1)) { g_err = "align_pairs_batch: basal_stale.src must name an earlier aligned read"; return BASAL_EINVAL; }
-        }
-        if (r.len > max_len) max_len = r.len;
-    }
+    if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_pairs_batch", &max_len)) return vrc;
     if (max_len == 0) max_len = 1;
     int rc;
     if ((rc = grow(c->d_bases, c->cap_bases, nbases + 64))) return rc;

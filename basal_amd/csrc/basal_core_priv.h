@@ -63,6 +63,8 @@ int basal_launch_align_carry(basal_core *c, const void *d_bases, uint64_t nbases
                              hipStream_t s, const basal_align_extra *ex);
 int basal_pe_enqueue(basal_core *c, const void *d_reads, const void *d_results, const void *d_stream, void *d_work, uint32_t npairs, void *d_pairs, void *d_recs,
                      uint64_t recs_cap, void *d_recs_used, void *d_stats, hipStream_t s);
+int basal_validate_batch(const basal_params &P, const basal_read *reads, uint32_t n, uint64_t nbases, const basal_stale *stales, uint32_t nstale, const char *who,
+                         uint32_t *max_len_out);  // the descriptor checks every host-buffer entry point makes (BASAL_EINVAL + message)
 int basal_ensure_launch_geometry(basal_core *c);  // sizes c->grid (largest grid any instantiation uses) and the core's own scratch
 int basal_report_guard(const unsigned int *guard);  // BASAL_OK, or BASAL_EDEVICE + message if the kernel's bounds ledger is not clean
 

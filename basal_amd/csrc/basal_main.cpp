@@ -741,12 +741,12 @@ void run_se_host(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, SeStats &st
         }
         results.assign(n, basal_result{});
         uint64_t cap = smode ? (uint64_t)n * 4 + 1024 : 0, used = 0;
-        for (;;) {
+        for (int attempt = 0;; attempt++) {
             stream.resize(cap ? cap : 1);
             uint8_t cy[2][2];
             memcpy(cy, carry, 4);
             int rc = al.run(bases.data(), bases.size(), descs.data(), (uint32_t)n, stales.data(), (uint32_t)stales.size(), smode, results.data(), stream.data(), cap, &used, cy);
-            if (rc == BASAL_EOVERFLOW) { cap = used + 1024; continue; }
+            if (rc == BASAL_EOVERFLOW && attempt < 4) { cap = std::max(used, cap) + 1024; continue; }  // (used = the capacity that fits, one retry is enough; never loop for ever)
             if (rc) die(std::string("align_batch: ") + basal_last_error());
             memcpy(carry, cy, 4);
             break;
@@ -973,14 +973,14 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
             uint64_t cap = pe_recs.size() > 2 * np + 4096 ? pe_recs.size() : 2 * np + 4096, used = 0;
             double g0 = now();
             uint32_t st9[9] = {0};
-            for (;;) {
+            for (int attempt = 0;; attempt++) {
                 pe_recs.resize(cap);
                 uint8_t cy[2][2];
                 memcpy(cy, carry, 4);
                 memset(st9, 0, sizeof st9);
                 int rc = basal_core_align_pairs_batch(al.core, bases.data(), bases.size(), descs.data(), (uint32_t)np, stales.data(), (uint32_t)stales.size(), pe_pairs.data(),
                                                       pe_recs.data(), cap, &used, st9, cy);
-                if (rc == BASAL_EOVERFLOW) { cap = used + used / 8 + 4096; continue; }
+                if (rc == BASAL_EOVERFLOW && attempt < 4) { cap = std::max(used, cap) + used / 8 + 4096; continue; }
                 if (rc) die(std::string("align_pairs_batch: ") + basal_last_error());
                 memcpy(carry, cy, 4);
                 break;
@@ -1007,13 +1007,13 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
         results.assign(2 * np, basal_result{});
         uint64_t cap = 16 * np + 4096, used = 0;
         double g0 = now();
-        for (;;) {
+        for (int attempt = 0;; attempt++) {
             stream.resize(cap);
             uint8_t cy[2][2];
             memcpy(cy, carry, 4);
             int rc = al.run(bases.data(), bases.size(), descs.data(), (uint32_t)(2 * np), stales.data(), (uint32_t)stales.size(), BASAL_STREAM_ALL, results.data(),
                             stream.data(), cap, &used, cy);
-            if (rc == BASAL_EOVERFLOW) { cap = used + 4096; continue; }
+            if (rc == BASAL_EOVERFLOW && attempt < 4) { cap = std::max(used, cap) + 4096; continue; }
             if (rc) die(std::string("align_batch: ") + basal_last_error());
             memcpy(carry, cy, 4);
             break;

@@ -170,16 +170,11 @@ extern "C" int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, u
                                        uint8_t carry[2][2]) {
     if (!m || (n && (!bases || !reads || !results))) { set_error("multi_align_batch: null argument"); return BASAL_EINVAL; }
     if (stream_mode != BASAL_STREAM_NONE && (!stream || !stream_used)) { set_error("multi_align_batch: stream buffers required for this stream_mode"); return BASAL_EINVAL; }
-    if (nbases > 0xFFFFFFFFull) { set_error("multi_align_batch: more than 4 GiB of bases in one batch"); return BASAL_EINVAL; }
     if (stream_used) *stream_used = 0;
     if (n == 0) return BASAL_OK;
     const int N = m->n;
     uint32_t max_len = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        if (reads[i].len > BASAL_MAXREADLEN || (reads[i].len && (uint64_t)reads[i].seq_off + reads[i].len > nbases)) { set_error("multi_align_batch: read descriptor out of range"); return BASAL_EINVAL; }
-        if (reads[i].stale_idx != BASAL_STALE_NONE && (!stales || reads[i].stale_idx >= nstale)) { set_error("multi_align_batch: stale_idx outside the stale table"); return BASAL_EINVAL; }
-        if (reads[i].len > max_len) max_len = reads[i].len;
-    }
+    if (int vrc = basal_validate_batch(m->cores[0]->p, reads, n, nbases, stales, nstale, "multi_align_batch", &max_len)) return vrc;
     if (max_len == 0) max_len = 1;
     const uint64_t shard_cap = (n + (uint64_t)N - 1) / (uint64_t)N;           // records every rank sends (the last ranks' tails are padding)
     const uint64_t stream_cap_dev = stream_mode == BASAL_STREAM_NONE ? 0 : (stream_cap + (uint64_t)N - 1) / (uint64_t)N + 1024;
@@ -209,7 +204,10 @@ extern "C" int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, u
             // (carry: the start offset inherited from the previous batch is the same on every GPU)
             rc = basal_launch_align_carry(c, v.bases, nbases, v.reads, (uint32_t)(hi - lo), nstale ? v.stales : nullptr, nstale, max_len, stream_mode, v.results, v.stream,
                                           stream_cap_dev, v.used, carry, v.st, &ex);
-            if (rc) return rc;
+            if (rc) {  // (the GPUs already started still read `iota` and the caller's buffers: let them finish before those go away)
+                for (int e = 0; e <= d; e++) { hipSetDevice(m->devices[(size_t)e]); hipStreamSynchronize(m->dev[(size_t)e].st); }
+                return rc;
+            }
         }
     }
     // 2. the one collective: every GPU's shard of records (and hit-stream records) to GPU 0
@@ -271,8 +269,12 @@ extern "C" int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, u
             } else overflow = true;
             at += used[(size_t)d];
         }
-        *stream_used = at + (overflow ? (uint64_t)N * 1024 : 0);
-        if (overflow) { set_error("multi_align_batch: hit stream too small; needed about " + std::to_string(*stream_used)); ret = BASAL_EOVERFLOW; }
+        // The caller's capacity is split evenly over the GPUs, so what it must offer next time is N x the LARGEST shard's need (a retry sized
+        // from the total would starve the fullest shard again, forever if the shards are uneven enough).
+        unsigned long long worst = 0;
+        for (int d = 0; d < N; d++) worst = std::max(worst, used[(size_t)d]);
+        *stream_used = overflow ? (uint64_t)N * (worst + 1024) : at;
+        if (overflow) { set_error("multi_align_batch: hit stream too small; a capacity of " + std::to_string(*stream_used) + " records fits every GPU's share"); ret = BASAL_EOVERFLOW; }
     }
     // carry: as basal_core_align_batch leaves it (the start offset after the last aligned read of each slot)
     if (carry) {
