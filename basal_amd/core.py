@@ -116,6 +116,7 @@ SYMBOLS = [
     ("basal_last_error", C.c_char_p, []),
     ("basal_core_set_contig_names", _i, [_vp, _P(C.c_char_p), _u32]),
     ("basal_pipe_create", _i, [_vp, _P(basal_pipe_opts), _P(_vp)]),
+    ("basal_pipe_create_multi", _i, [_P(_vp), _i, _P(basal_pipe_opts), _P(_vp)]),
     ("basal_pipe_destroy", None, [_vp]),
     ("basal_pipe_acquire", _i, [_vp, _P(_vp), _P(_vp)]),
     ("basal_pipe_submit_text", _i, [_vp, _u64, _i, _u32, _u32]),
@@ -386,12 +387,17 @@ class Pipe:
     """basal_pipe_t: batches of raw read text / raw read tables / prepared reads in, SAM text / basal_result records out."""
 
     def __init__(self, core, depth=3, max_reads=1 << 16, max_bytes=32 << 20, output=PIPE_OUT_SAM):
+        """core: one Core, or a list of Cores (one per GPU, all staged alike): batches then fan out over them (basal_pipe_create_multi)."""
         self.core = core
         self.h = C.c_void_p()
         self.max_reads = (max_reads + 4095) & ~4095
         self.max_bytes = (max_bytes + 4095) & ~4095
         o = basal_pipe_opts(depth, max_reads, max_bytes, output, 0)
-        _check(lib().basal_pipe_create(core.h, C.byref(o), C.byref(self.h)), "pipe_create")
+        if isinstance(core, (list, tuple)):
+            arr = (C.c_void_p * len(core))(*[c.h for c in core])
+            _check(lib().basal_pipe_create_multi(arr, len(core), C.byref(o), C.byref(self.h)), "pipe_create_multi")
+        else:
+            _check(lib().basal_pipe_create(core.h, C.byref(o), C.byref(self.h)), "pipe_create")
 
     def close(self):
         if self.h:

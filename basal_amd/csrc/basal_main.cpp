@@ -1141,23 +1141,36 @@ int main(int argc, char **argv) {
     }
     basal_core_t *core = nullptr;
     basal_multi_t *multi = nullptr;
+    std::vector<basal_core_t *> cores;  // single-end on several GPUs: one core per GPU behind ONE batch pipeline (basal_pipe_create_multi)
     if (cli.devices.empty()) cli.devices.push_back(cli.device);
-    const bool several = cli.devices.size() > 1 || getenv("BASAL_FORCE_MULTI") != nullptr;  // (the variable: the sharded path on a one-GPU box, for tests)
-    if (several) {
+    const bool several = cli.devices.size() > 1 || getenv("BASAL_FORCE_MULTI") != nullptr;  // (the variable: the several-GPU paths on a one-GPU box, for tests)
+    // Single-end: whole batches fan out over the GPUs, each through the device-side pipeline (text in, SAM out); a GPU may be listed twice
+    // (two cores on one GPU: how the tests drive two ranks on a one-GPU box). Paired-end: the batch is sharded over the GPUs and the records
+    // come back through one RCCL gather (basal_multi_*); BASAL_MULTI_HOST=1 sends single-end reads that way too (host-side QC and SAM text).
+    const bool se_pipes = !P.pairend && !getenv("BASAL_MULTI_HOST");
+    if (several && !se_pipes) {
         if (basal_multi_create(&P, cli.devices.data(), (int)cli.devices.size(), &multi)) die(std::string("cannot set up the GPUs: ") + basal_last_error());
         core = basal_multi_core(multi, 0);
-    } else if (basal_core_create(&P, cli.device, &core)) die(std::string("cannot create the GPU core: ") + basal_last_error());
+    } else {
+        for (int dv : cli.devices) {
+            basal_core_t *c1 = nullptr;
+            if (basal_core_create(&P, dv, &c1)) die(std::string("cannot create the GPU core: ") + basal_last_error());
+            cores.push_back(c1);
+            if (P.pairend || !several) break;
+        }
+        core = cores[0];
+    }
     // single-end: the pipeline's buffers are page-locked by a helper thread while the reference is read and staged
     SePlan plan;
     basal_pipe_t *pipe = nullptr;
     std::thread pipe_thread;
     std::string pipe_err;
     double t_pipe = 0;
-    if (!P.pairend && !several) {
+    if (!P.pairend && !multi) {
         plan = plan_se(cli);
         pipe_thread = std::thread([&] {
             const double a0 = now();
-            if (basal_pipe_create(core, &plan.po, &pipe)) pipe_err = basal_last_error();
+            if (basal_pipe_create_multi(cores.data(), (int)cores.size(), &plan.po, &pipe)) pipe_err = basal_last_error();
             t_pipe = now() - a0;
         });
     }
@@ -1167,13 +1180,23 @@ int main(int argc, char **argv) {
     double t1 = now();
     uint32_t mk = 0;
     if (cli.cpu_index && basal_host_ref_build_index(R, &P, cli.threads)) die(basal_last_error());
-    if (several) { if (basal_multi_upload(multi, R, cli.cpu_index ? 0 : 1, &mk)) die(basal_last_error()); }
-    else if (basal_host_ref_upload(R, core, cli.cpu_index ? 0 : 1, &mk)) die(basal_last_error());
-    {
-        const uint32_t nc = basal_host_ref_ncontig(R);
-        std::vector<const char *> names(nc);
-        for (uint32_t i = 0; i < nc; i++) names[i] = basal_host_ref_name(R, i);
-        if (basal_core_set_contig_names(core, names.data(), nc)) die(basal_last_error());
+    const uint32_t nc_names = basal_host_ref_ncontig(R);
+    std::vector<const char *> names(nc_names);
+    for (uint32_t i = 0; i < nc_names; i++) names[i] = basal_host_ref_name(R, i);
+    if (multi) {
+        if (basal_multi_upload(multi, R, cli.cpu_index ? 0 : 1, &mk)) die(basal_last_error());
+        if (basal_core_set_contig_names(core, names.data(), nc_names)) die(basal_last_error());
+    } else {  // every GPU stages the reference and builds its index at the same time, one host thread each
+        std::vector<std::string> errs(cores.size());
+        std::vector<uint32_t> mks(cores.size(), 0);
+        std::vector<std::thread> th;
+        for (size_t g = 0; g < cores.size(); g++)
+            th.emplace_back([&, g] {
+                if (basal_host_ref_upload(R, cores[g], cli.cpu_index ? 0 : 1, &mks[g]) || basal_core_set_contig_names(cores[g], names.data(), nc_names)) errs[g] = basal_last_error();
+            });
+        for (auto &t : th) t.join();
+        for (auto &e : errs) if (!e.empty()) die(e);
+        mk = mks[0];
     }
     double t2 = now();
     if (cli.verbose >= 1)
@@ -1210,7 +1233,7 @@ int main(int argc, char **argv) {
         uint32_t pst[9] = {0};
         uint64_t n_pairs = 0;
         double t_gpu = 0;
-        Aligner al{several ? nullptr : core, multi};
+        Aligner al{multi ? nullptr : core, multi};
         const double tp0 = now();
         run_pe(cli, al, R, out, pst, n_pairs, t_gpu);
         out.close();
@@ -1224,7 +1247,7 @@ int main(int argc, char **argv) {
     } else {
         SeStats st;
         double t_wait = 0;
-        if (several) {
+        if (multi) {
             Aligner al{nullptr, multi};
             run_se_host(cli, al, R, out, st);
         } else {
@@ -1252,7 +1275,7 @@ int main(int argc, char **argv) {
     if (!getenv("BASAL_CLEAN_EXIT")) _exit(0);  // everything is written: leave the gigabytes of page-locked and device memory to the OS
     if (pipe) basal_pipe_destroy(pipe);
     if (multi) basal_multi_destroy(multi);
-    else basal_core_destroy(core);
+    else for (auto *c1 : cores) basal_core_destroy(c1);
     basal_host_ref_free(R);
     return 0;
 }

@@ -12,6 +12,7 @@
 
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "basal_core_priv.h"
@@ -142,12 +143,20 @@ extern "C" basal_core_t *basal_multi_core(basal_multi_t *m, int rank) { return m
 // the whole reference + index on every GPU
 extern "C" int basal_multi_upload(basal_multi_t *m, const basal_ref_t *r, int build_index_on_gpu, uint32_t *max_kmer_num) {
     if (!m || !r) { set_error("multi_upload: null argument"); return BASAL_EINVAL; }
-    for (int d = 0; d < m->n; d++) {
-        uint32_t mk = 0;
-        int rc = basal_host_ref_upload(r, m->cores[(size_t)d], build_index_on_gpu, &mk);
-        if (rc) return rc;
-        if (max_kmer_num) *max_kmer_num = mk;
-    }
+    // every GPU stages the reference and builds its index at the same time, one host thread each
+    std::vector<int> rcs((size_t)m->n, 0);
+    std::vector<uint32_t> mks((size_t)m->n, 0);
+    std::vector<std::string> errs((size_t)m->n);
+    std::vector<std::thread> th;
+    for (int d = 0; d < m->n; d++)
+        th.emplace_back([&, d] {
+            rcs[(size_t)d] = basal_host_ref_upload(r, m->cores[(size_t)d], build_index_on_gpu, &mks[(size_t)d]);
+            if (rcs[(size_t)d]) errs[(size_t)d] = basal_last_error();  // (the message is per thread)
+        });
+    for (auto &t : th) t.join();
+    for (int d = 0; d < m->n; d++)
+        if (rcs[(size_t)d]) { set_error(errs[(size_t)d]); return rcs[(size_t)d]; }
+    if (max_kmer_num) *max_kmer_num = mks[0];
     return BASAL_OK;
 }
 

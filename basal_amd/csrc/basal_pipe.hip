@@ -41,6 +41,7 @@ enum { ST_FREE = 0, ST_ACQUIRED, ST_INFLIGHT, ST_HELD };
 
 struct Slot {
     SlotDev d;
+    int dev = 0;  // index into basal_pipe::devs: the GPU this slot's buffers live on
     uint8_t *h_blob = nullptr;
     basal_rawread *h_raw = nullptr;
     uint8_t *h_out = nullptr;
@@ -60,18 +61,33 @@ struct Slot {
 
 }  // namespace
 
-struct basal_pipe {
+// one GPU of a pipe: its core, its ring of carry states and its four streams
+struct PipeDev {
     basal_core *c = nullptr;
+    PrepShared sh;
+    hipStream_t st_in = nullptr, st_comp = nullptr, st_out = nullptr, st_cnt = nullptr;  // st_cnt: the few bytes of counters per batch (the host sizes the output copy from them; they must not queue behind an output copy)
+};
+
+// A pipe over one GPU, or over several (basal_pipe_create_multi): whole batches fan out over the GPUs, the way the reference's worker
+// threads each take a whole batch (main.cpp:60-92), every batch staying on one GPU from its text to its SAM bytes -- H2D bytes per read do
+// not grow with the number of GPUs, and no GPU waits for another except for the carry state: what a SingleAlign object carries from read
+// to read (CarryState, 470 KB) travels from the GPU that prepared batch b-1 to the one that prepares batch b, behind b-1's prep kernels
+// (the align kernels, 90 % of the work, overlap freely). One sequence of batch numbers, one order of results: the output is the
+// one-GPU output, byte for byte.
+struct basal_pipe {
+    std::vector<PipeDev> devs;
+    basal_core *c = nullptr;  // devs[0].c (parameters, limits)
     basal_pipe_opts o;
     PrepConst k;
-    PrepShared sh;
+    uint32_t ncarry = 0;            // carry states per GPU, indexed by batch number: batch b reads [b % ncarry] and writes [(b + 1) % ncarry]
+    std::vector<int> carry_dev;     // [ncarry]: the GPU that holds the valid copy of that state (-1: every GPU does -- the initial state)
+    std::vector<int> carry_slot;    // [ncarry]: the slot whose prep kernels wrote it (-1: none pending), for the event a reader on another GPU waits for
     std::vector<Slot> slots;
     std::mutex m;
     std::condition_variable cv;
-    int acquired = -1, held = -1;
+    int acquired = -1, held = -1, last_slot = -1;
     std::deque<int> inflight;
     uint32_t next_batch = 0;
-    hipStream_t st_in = nullptr, st_comp = nullptr, st_out = nullptr, st_cnt = nullptr;  // st_cnt: the few bytes of counters per batch (the host sizes the output copy from them; they must not queue behind an output copy)
     uint32_t read_end = 0xFFFFFFFFu;
     bool broken = false;     // a batch was refused (or basal_pipe_stop): no acquire / submit / collect until basal_pipe_rewind
     uint32_t rewind_to = 0;  // the batch number the pipe continues from after a rewind
@@ -113,19 +129,25 @@ static void free_slot(Slot &s) {
 
 extern "C" void basal_pipe_destroy(basal_pipe_t *p) {
     if (!p) return;
-    hipSetDevice(p->c->device);
-    hipDeviceSynchronize();
-    for (auto &s : p->slots) free_slot(s);
-    for (uint32_t i = 0; i < p->sh.ncarry; i++) hipFree(p->sh.carry[i]);
-    if (p->st_in) hipStreamDestroy(p->st_in);
-    if (p->st_comp) hipStreamDestroy(p->st_comp);
-    if (p->st_out) hipStreamDestroy(p->st_out);
-    if (p->st_cnt) hipStreamDestroy(p->st_cnt);
+    for (auto &v : p->devs) { hipSetDevice(v.c->device); hipDeviceSynchronize(); }
+    for (auto &s : p->slots) { hipSetDevice(p->devs[(size_t)s.dev].c->device); free_slot(s); }
+    for (auto &v : p->devs) {
+        hipSetDevice(v.c->device);
+        for (uint32_t i = 0; i < v.sh.ncarry; i++) hipFree(v.sh.carry[i]);
+        if (v.st_in) hipStreamDestroy(v.st_in);
+        if (v.st_comp) hipStreamDestroy(v.st_comp);
+        if (v.st_out) hipStreamDestroy(v.st_out);
+        if (v.st_cnt) hipStreamDestroy(v.st_cnt);
+    }
     delete p;
 }
 
-extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basal_pipe_t **out) {
-    if (!c || !out) { set_error("pipe_create: null argument"); return BASAL_EINVAL; }
+extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basal_pipe_t **out) { return basal_pipe_create_multi(&c, 1, o, out); }
+
+extern "C" int basal_pipe_create_multi(basal_core_t *const *cores, int ncores, const basal_pipe_opts *o, basal_pipe_t **out) {
+    if (!cores || ncores < 1 || ncores > 16 || !out) { set_error("pipe_create: null argument, or not 1..16 cores"); return BASAL_EINVAL; }
+    for (int g = 0; g < ncores; g++) if (!cores[g]) { set_error("pipe_create: null core"); return BASAL_EINVAL; }
+    basal_core *c = cores[0];
     basal_pipe_opts op;
     memset(&op, 0, sizeof op);
     if (o) op = *o;
@@ -137,24 +159,39 @@ extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basa
     op.max_bytes = (op.max_bytes + 4095ull) & ~4095ull;
     if (op.max_bytes >= 0xFFFFF000ull) { set_error("pipe_create: max_bytes must stay below 4 GiB (32-bit offsets inside a batch)"); return BASAL_EINVAL; }
     if (op.output > BASAL_PIPE_OUT_RESULTS) { set_error("pipe_create: bad output mode"); return BASAL_EINVAL; }
-    HIP_TRYQ(hipSetDevice(c->device));
-    int rc = basal_ensure_launch_geometry(c);
-    if (rc) return rc;
     basal_pipe *p = new basal_pipe();
     p->c = c;
     p->o = op;
     prep_make_const(c->p, p->k);
-    p->sh.ncarry = op.depth + 1;
-    p->slots.resize(op.depth);
+    p->devs.resize((size_t)ncores);
+    const uint32_t nslots = op.depth * (uint32_t)ncores;  // `depth` batches in flight per GPU
+    p->ncarry = nslots + 1;
+    if (p->ncarry > sizeof(p->devs[0].sh.carry) / sizeof(p->devs[0].sh.carry[0])) { basal_pipe_destroy(p); set_error("pipe_create: depth x GPUs must stay below 128 batches in flight"); return BASAL_EINVAL; }
+    p->carry_dev.assign(p->ncarry, -1);
+    p->carry_slot.assign(p->ncarry, -1);
+    p->slots.resize(nslots);
 #define TRYD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); basal_pipe_destroy(p); return e_ == hipErrorOutOfMemory ? BASAL_ENOMEM : BASAL_EDEVICE; } } while (0)
-    for (uint32_t i = 0; i < p->sh.ncarry; i++) {
-        TRYD(hipMalloc(&p->sh.carry[i], sizeof(CarryState)));
-        TRYD(hipMemset(p->sh.carry[i], 0, sizeof(CarryState)));
+    for (int g = 0; g < ncores; g++) {
+        PipeDev &v = p->devs[(size_t)g];
+        v.c = cores[g];
+        TRYD(hipSetDevice(v.c->device));
+        int rc = basal_ensure_launch_geometry(v.c);
+        if (rc) { basal_pipe_destroy(p); return rc; }
+        v.sh.ncarry = p->ncarry;
+        for (uint32_t i = 0; i < p->ncarry; i++) {
+            TRYD(hipMalloc(&v.sh.carry[i], sizeof(CarryState)));
+            TRYD(hipMemset(v.sh.carry[i], 0, sizeof(CarryState)));
+        }
     }
     const uint32_t mr = op.max_reads;
     const size_t cub = prep_cub_tmp_bytes(mr, op.max_bytes);
     const bool sam = op.output == BASAL_PIPE_OUT_SAM;
-    for (auto &s : p->slots) {
+    const unsigned host_flags = ncores > 1 ? hipHostMallocPortable : hipHostMallocDefault;  // (page-locked for every GPU's copy engines)
+    for (uint32_t si = 0; si < nslots; si++) {
+        Slot &s = p->slots[si];
+        s.dev = (int)(si % (uint32_t)ncores);  // consecutive slots on consecutive GPUs: consecutive batches fan out
+        basal_core *cg = p->devs[(size_t)s.dev].c;
+        TRYD(hipSetDevice(cg->device));
         SlotDev &d = s.d;
         d.text_cap = op.max_bytes;
         TRYD(hipMalloc(&d.text, op.max_bytes + 1024));
@@ -164,7 +201,7 @@ extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basa
         TRYD(hipMalloc(&d.cnt, sizeof(BatchCounters)));
         TRYD(hipMalloc(&d.counter, 32 * sizeof(unsigned int)));
         TRYD(hipMemset(d.counter, 0, 32 * sizeof(unsigned int)));
-        TRYD(hipMalloc(&d.scratch, (size_t)c->grid * 4 * c->scratch_per_wave * sizeof(basal_hit)));
+        TRYD(hipMalloc(&d.scratch, (size_t)cg->grid * 4 * cg->scratch_per_wave * sizeof(basal_hit)));
         if (sam) {
             TRYD(hipMalloc(&d.aux, (size_t)mr * sizeof(ReadAux)));
             TRYD(hipMalloc(&d.stales, (size_t)mr * sizeof(basal_stale)));
@@ -186,26 +223,27 @@ extern "C" int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basa
             }
             s.h_out_cap = d.out_cap;
         } else s.h_out_cap = (size_t)mr * sizeof(basal_result);
-        TRYD(hipHostMalloc(&s.h_blob, op.max_bytes, hipHostMallocDefault));
-        TRYD(hipHostMalloc(&s.h_raw, (size_t)mr * sizeof(basal_rawread), hipHostMallocDefault));
-        TRYD(hipHostMalloc(&s.h_out, s.h_out_cap, hipHostMallocDefault));
-        TRYD(hipHostMalloc(&s.h_cnt, sizeof(BatchCounters), hipHostMallocDefault));
-        TRYD(hipHostMalloc(&s.h_guard, 24 * sizeof(unsigned int), hipHostMallocDefault));
+        TRYD(hipHostMalloc(&s.h_blob, op.max_bytes, host_flags));
+        TRYD(hipHostMalloc(&s.h_raw, (size_t)mr * sizeof(basal_rawread), host_flags));
+        TRYD(hipHostMalloc(&s.h_out, s.h_out_cap, host_flags));
+        TRYD(hipHostMalloc(&s.h_cnt, sizeof(BatchCounters), host_flags));
+        TRYD(hipHostMalloc(&s.h_guard, 24 * sizeof(unsigned int), host_flags));
         for (int i = 0; i < EV_N; i++) TRYD(hipEventCreate(&s.ev[i]));
     }
-    {
+    for (auto &v : p->devs) {
         // HIP multiplexes streams onto a few hardware queues (4 by default), and two streams on one queue run in submission order --
         // the copy-in stream and the kernel stream sharing a queue would undo the whole pipeline (measured: exactly that happened).
         // Streams of different priority get queues of their own, so the four streams are spread over the priority levels.
+        TRYD(hipSetDevice(v.c->device));
         int lo = 0, hi = 0;
         TRYD(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least urgent (numerically largest), hi = most urgent
         const char *e = getenv("BASAL_PIPE_PRIO");
         int pin = hi, pcomp = (lo + hi) / 2, pout = lo, pcnt = hi;
         if (e && strlen(e) == 4) { auto lv = [&](char ch) { return ch == 'h' ? hi : ch == 'l' ? lo : (lo + hi) / 2; }; pin = lv(e[0]); pcomp = lv(e[1]); pout = lv(e[2]); pcnt = lv(e[3]); }
-        TRYD(hipStreamCreateWithPriority(&p->st_in, hipStreamNonBlocking, pin));
-        TRYD(hipStreamCreateWithPriority(&p->st_comp, hipStreamNonBlocking, pcomp));
-        TRYD(hipStreamCreateWithPriority(&p->st_out, hipStreamNonBlocking, pout));
-        TRYD(hipStreamCreateWithPriority(&p->st_cnt, hipStreamNonBlocking, pcnt));
+        TRYD(hipStreamCreateWithPriority(&v.st_in, hipStreamNonBlocking, pin));
+        TRYD(hipStreamCreateWithPriority(&v.st_comp, hipStreamNonBlocking, pcomp));
+        TRYD(hipStreamCreateWithPriority(&v.st_out, hipStreamNonBlocking, pout));
+        TRYD(hipStreamCreateWithPriority(&v.st_cnt, hipStreamNonBlocking, pcnt));
     }
 #undef TRYD
     *out = p;
@@ -218,14 +256,17 @@ extern "C" int basal_pipe_acquire(basal_pipe_t *p, uint8_t **blob, basal_rawread
     if (p->acquired >= 0) { set_error("pipe_acquire: the acquired slot has not been submitted"); return BASAL_ESTATE; }
     for (;;) {
         if (p->broken) { set_error("pipe_acquire: the pipe is stopped (a batch was refused): call basal_pipe_rewind"); return BASAL_ESTATE; }
-        for (size_t i = 0; i < p->slots.size(); i++)
+        for (size_t k = 1; k <= p->slots.size(); k++) {  // (from the slot behind the last one taken: consecutive batches go to consecutive GPUs)
+            const size_t i = ((size_t)(p->last_slot + 1) + k - 1) % p->slots.size();
             if (p->slots[i].state == ST_FREE) {
                 p->slots[i].state = ST_ACQUIRED;
                 p->acquired = (int)i;
+                p->last_slot = (int)i;
                 if (blob) *blob = p->slots[i].h_blob;
                 if (raw) *raw = p->slots[i].h_raw;
                 return BASAL_OK;
             }
+        }
         // every slot is in flight or held by the collector: wait for a collect to release one
         p->cv.wait(lk);
     }
@@ -234,6 +275,8 @@ extern "C" int basal_pipe_acquire(basal_pipe_t *p, uint8_t **blob, basal_rawread
 // queue the D2H copy of a finished batch's output if its size is known (its counters have arrived) and it fits
 static int try_queue_output(basal_pipe *p, Slot &s, bool wait) {
     if (s.out_queued) return BASAL_OK;
+    PipeDev &v = p->devs[(size_t)s.dev];
+    HIP_TRYQ(hipSetDevice(v.c->device));
     if (wait) HIP_TRYQ(hipEventSynchronize(s.ev[EV_COUNTERS]));
     else if (hipEventQuery(s.ev[EV_COUNTERS]) != hipSuccess) return BASAL_OK;
     if (p->o.output == BASAL_PIPE_OUT_SAM) {
@@ -244,19 +287,20 @@ static int try_queue_output(basal_pipe *p, Slot &s, bool wait) {
             hipHostFree(s.h_out);
             s.h_out = nullptr;
             s.h_out_cap = cn.out_bytes + cn.out_bytes / 4;
-            HIP_TRYQ(hipHostMalloc(&s.h_out, s.h_out_cap, hipHostMallocDefault));
+            HIP_TRYQ(hipHostMalloc(&s.h_out, s.h_out_cap, p->devs.size() > 1 ? hipHostMallocPortable : hipHostMallocDefault));
         }
         s.out_bytes = cn.out_bytes;
-        HIP_TRYQ(hipEventRecord(s.ev[EV_OUT0], p->st_out));
-        if (s.out_bytes) HIP_TRYQ(hipMemcpyAsync(s.h_out, s.d.out, s.out_bytes, hipMemcpyDeviceToHost, p->st_out));
+        HIP_TRYQ(hipEventRecord(s.ev[EV_OUT0], v.st_out));
+        if (s.out_bytes) HIP_TRYQ(hipMemcpyAsync(s.h_out, s.d.out, s.out_bytes, hipMemcpyDeviceToHost, v.st_out));
     }
-    HIP_TRYQ(hipEventRecord(s.ev[EV_OUT], p->st_out));
+    HIP_TRYQ(hipEventRecord(s.ev[EV_OUT], v.st_out));
     s.out_queued = true;
     return BASAL_OK;
 }
 
 static int queue_align(basal_pipe *p, Slot &s) {
-    basal_core *c = p->c;
+    PipeDev &v = p->devs[(size_t)s.dev];
+    basal_core *c = v.c;
     SlotDev &d = s.d;
     const uint32_t mr = p->o.max_reads;
     const int smode = p->o.output == BASAL_PIPE_OUT_SAM && c->p.report_repeat_hits == 2 ? BASAL_STREAM_BEST : BASAL_STREAM_NONE;
@@ -264,7 +308,7 @@ static int queue_align(basal_pipe *p, Slot &s) {
         basal_align_extra ex;
         ex.counter = d.counter;
         ex.scratch = d.scratch;
-        return basal_launch_align(c, d.text, s.nbytes, d.raw, s.n_host, nullptr, 0, s.max_len, BASAL_STREAM_NONE, d.results, nullptr, 0, &d.cnt->stream_used, p->st_comp, &ex);
+        return basal_launch_align(c, d.text, s.nbytes, d.raw, s.n_host, nullptr, 0, s.max_len, BASAL_STREAM_NONE, d.results, nullptr, 0, &d.cnt->stream_used, v.st_comp, &ex);
     }
     static const uint32_t cls_len[3] = {128, 256, BASAL_MAXREADLEN};
     for (int cl = 0; cl < 3; cl++) {
@@ -275,7 +319,7 @@ static int queue_align(basal_pipe *p, Slot &s) {
         ex.ghost_base = mr;
         ex.counter = d.counter;
         ex.scratch = d.scratch;
-        int rc = basal_launch_align(c, d.text, d.text_cap + 1024, d.desc, mr, d.stales, mr, cls_len[cl], smode, d.results, d.stream, d.stream_cap, &d.cnt->stream_used, p->st_comp, &ex);
+        int rc = basal_launch_align(c, d.text, d.text_cap + 1024, d.desc, mr, d.stales, mr, cls_len[cl], smode, d.results, d.stream, d.stream_cap, &d.cnt->stream_used, v.st_comp, &ex);
         if (rc) return rc;
     }
     return BASAL_OK;
@@ -283,7 +327,6 @@ static int queue_align(basal_pipe *p, Slot &s) {
 
 static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, int format, uint32_t first_index, uint32_t readset, uint32_t max_len) {
     if (!p) { set_error("pipe_submit: null argument"); return BASAL_EINVAL; }
-    basal_core *c = p->c;
     int si;
     bool broken;
     {
@@ -293,6 +336,8 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     }
     if (si < 0) { set_error("pipe_submit: no acquired slot (call basal_pipe_acquire first)"); return BASAL_ESTATE; }
     Slot &s = p->slots[(size_t)si];
+    PipeDev &v = p->devs[(size_t)s.dev];
+    basal_core *c = v.c;
     auto fail = [&](int rc) {
         std::lock_guard<std::mutex> lk(p->m);
         s.state = ST_FREE;
@@ -304,8 +349,8 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     // (the pipe may have been created while the reference was still being staged: page-locking its buffers takes a while)
     if (!c->have_ref || !c->have_index) { set_error("pipe_submit: stage the reference and the index first"); return fail(BASAL_ESTATE); }
     if (p->o.output == BASAL_PIPE_OUT_SAM && (!c->d_names || c->n_names != c->ncontig)) { set_error("pipe_submit: SAM output needs basal_core_set_contig_names first"); return fail(BASAL_ESTATE); }
-    p->sh.names = c->d_names;
-    p->sh.name_off = c->d_name_off;
+    v.sh.names = c->d_names;
+    v.sh.name_off = c->d_name_off;
     if (nbytes > p->o.max_bytes || n > p->o.max_reads) { set_error("pipe_submit: batch larger than the pipe's max_bytes / max_reads"); return fail(BASAL_EINVAL); }
     if ((mode == MODE_PREPARED) != (p->o.output == BASAL_PIPE_OUT_RESULTS)) { set_error("pipe_submit: prepared reads go with BASAL_PIPE_OUT_RESULTS, text and records with BASAL_PIPE_OUT_SAM"); return fail(BASAL_EINVAL); }
     if (hipSetDevice(c->device) != hipSuccess) { set_error("pipe_submit: hipSetDevice failed"); return fail(BASAL_EDEVICE); }
@@ -313,45 +358,54 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     const uint32_t mr = p->o.max_reads;
     s.mode = mode; s.nbytes = nbytes; s.n_host = n; s.max_len = max_len; s.out_queued = false; s.out_bytes = 0;
     uint32_t bno;
+    int src_dev, src_slot;
     {
         std::lock_guard<std::mutex> lk(p->m);
         bno = p->next_batch;
+        src_dev = p->carry_dev[bno % p->ncarry];
+        src_slot = p->carry_slot[bno % p->ncarry];
     }
     s.batch_no = bno;
 #define TRYS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return fail(BASAL_EDEVICE); } } while (0)
 #define TRYR(x) do { int r_ = (x); if (r_) return fail(r_); } while (0)
     // copies in
-    TRYS(hipEventRecord(s.ev[EV_START], p->st_in));
-    if (nbytes) TRYS(hipMemcpyAsync(d.text, s.h_blob, nbytes, hipMemcpyHostToDevice, p->st_in));
-    if (mode == MODE_RECORDS && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_rawread), hipMemcpyHostToDevice, p->st_in));
-    if (mode == MODE_PREPARED && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, p->st_in));
-    TRYS(hipEventRecord(s.ev[EV_H2D], p->st_in));
+    TRYS(hipEventRecord(s.ev[EV_START], v.st_in));
+    if (nbytes) TRYS(hipMemcpyAsync(d.text, s.h_blob, nbytes, hipMemcpyHostToDevice, v.st_in));
+    if (mode == MODE_RECORDS && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_rawread), hipMemcpyHostToDevice, v.st_in));
+    if (mode == MODE_PREPARED && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, v.st_in));
+    TRYS(hipEventRecord(s.ev[EV_H2D], v.st_in));
     // kernels (this stream also keeps the batches' carry states in order)
-    TRYS(hipStreamWaitEvent(p->st_comp, s.ev[EV_H2D], 0));
-    TRYS(hipEventRecord(s.ev[EV_COMP0], p->st_comp));
-    TRYS(hipMemsetAsync(d.cnt, 0, sizeof(BatchCounters), p->st_comp));
-    if (mode != MODE_PREPARED) {
-        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, p->sh, bno, nbytes, format, first_index, p->read_end, readset, mr, p->st_comp));
-        else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, p->st_comp));
-        TRYR(prep_enqueue_filter(c, p->k, d, p->sh, bno, mr, true, 0, p->st_comp));
+    TRYS(hipStreamWaitEvent(v.st_comp, s.ev[EV_H2D], 0));
+    TRYS(hipEventRecord(s.ev[EV_COMP0], v.st_comp));
+    TRYS(hipMemsetAsync(d.cnt, 0, sizeof(BatchCounters), v.st_comp));
+    if (mode != MODE_PREPARED && src_dev >= 0 && src_dev != s.dev) {
+        // the state this batch starts from was written on another GPU, by the prep kernels of the batch before: fetch it behind them
+        PipeDev &w = p->devs[(size_t)src_dev];
+        if (src_slot >= 0) TRYS(hipStreamWaitEvent(v.st_comp, p->slots[(size_t)src_slot].ev[EV_PREP], 0));
+        TRYS(hipMemcpyPeerAsync(v.sh.carry[bno % p->ncarry], c->device, w.sh.carry[bno % p->ncarry], w.c->device, sizeof(CarryState), v.st_comp));
     }
-    TRYS(hipEventRecord(s.ev[EV_PREP], p->st_comp));
+    if (mode != MODE_PREPARED) {
+        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, v.sh, bno, nbytes, format, first_index, p->read_end, readset, mr, v.st_comp));
+        else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, v.st_comp));
+        TRYR(prep_enqueue_filter(c, p->k, d, v.sh, bno, mr, true, 0, v.st_comp));
+    }
+    TRYS(hipEventRecord(s.ev[EV_PREP], v.st_comp));
     TRYR(queue_align(p, s));
-    TRYS(hipEventRecord(s.ev[EV_ALIGN], p->st_comp));
-    if (mode != MODE_PREPARED) TRYR(prep_enqueue_format(c, p->k, d, p->sh, mr, p->st_comp));
-    TRYS(hipEventRecord(s.ev[EV_FORMAT], p->st_comp));
+    TRYS(hipEventRecord(s.ev[EV_ALIGN], v.st_comp));
+    if (mode != MODE_PREPARED) TRYR(prep_enqueue_format(c, p->k, d, v.sh, mr, v.st_comp));
+    TRYS(hipEventRecord(s.ev[EV_FORMAT], v.st_comp));
     // copies out: the counters (and the guard ledger) always; the output itself once its size is known
-    TRYS(hipStreamWaitEvent(p->st_cnt, s.ev[EV_FORMAT], 0));
-    TRYS(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, p->st_cnt));
-    TRYS(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, p->st_cnt));
-    TRYS(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), p->st_cnt));
-    TRYS(hipEventRecord(s.ev[EV_COUNTERS], p->st_cnt));
+    TRYS(hipStreamWaitEvent(v.st_cnt, s.ev[EV_FORMAT], 0));
+    TRYS(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, v.st_cnt));
+    TRYS(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, v.st_cnt));
+    TRYS(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), v.st_cnt));
+    TRYS(hipEventRecord(s.ev[EV_COUNTERS], v.st_cnt));
     if (mode == MODE_PREPARED) {  // the size of the output is known: queue its copy right behind the kernel
-        TRYS(hipStreamWaitEvent(p->st_out, s.ev[EV_FORMAT], 0));
-        TRYS(hipEventRecord(s.ev[EV_OUT0], p->st_out));
-        if (n) TRYS(hipMemcpyAsync(s.h_out, d.results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, p->st_out));
+        TRYS(hipStreamWaitEvent(v.st_out, s.ev[EV_FORMAT], 0));
+        TRYS(hipEventRecord(s.ev[EV_OUT0], v.st_out));
+        if (n) TRYS(hipMemcpyAsync(s.h_out, d.results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, v.st_out));
         s.out_bytes = (uint64_t)n * sizeof(basal_result);
-        TRYS(hipEventRecord(s.ev[EV_OUT], p->st_out));
+        TRYS(hipEventRecord(s.ev[EV_OUT], v.st_out));
         s.out_queued = true;
     }
 #undef TRYS
@@ -362,6 +416,10 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
         p->inflight.push_back(si);
         p->acquired = -1;
         p->next_batch = bno + 1;
+        if (mode != MODE_PREPARED) {  // the state the next batch starts from: written here, by this slot's prep kernels
+            p->carry_dev[(bno + 1) % p->ncarry] = s.dev;
+            p->carry_slot[(bno + 1) % p->ncarry] = si;
+        }
         // the batches in front may have finished meanwhile: start the copy of their output now rather than when they are collected
         for (int j : p->inflight)
             if (j != si && !p->slots[(size_t)j].collecting) try_queue_output(p, p->slots[(size_t)j], false);
@@ -383,10 +441,15 @@ extern "C" int basal_pipe_set_read_range(basal_pipe_t *p, uint32_t next_index, u
     if (!p) { set_error("pipe_set_read_range: null argument"); return BASAL_EINVAL; }
     std::lock_guard<std::mutex> lk(p->m);
     if (!p->inflight.empty() || p->acquired >= 0) { set_error("pipe_set_read_range: batches in flight"); return BASAL_ESTATE; }
-    HIP_TRYQ(hipSetDevice(p->c->device));
-    HIP_TRYQ(hipDeviceSynchronize());
-    CarryState *cs = p->sh.carry[p->next_batch % p->sh.ncarry];
-    HIP_TRYQ(hipMemcpy(&cs->next_index, &next_index, sizeof(uint32_t), hipMemcpyHostToDevice));
+    const uint32_t at = p->next_batch % p->ncarry;
+    const int home = p->carry_dev[at];
+    for (size_t g = 0; g < p->devs.size(); g++) {  // (the state the next batch starts from: on the GPU that holds it, or on all of them before the first batch)
+        if (home >= 0 && (int)g != home) continue;
+        PipeDev &v = p->devs[g];
+        HIP_TRYQ(hipSetDevice(v.c->device));
+        HIP_TRYQ(hipDeviceSynchronize());
+        HIP_TRYQ(hipMemcpy(&v.sh.carry[at]->next_index, &next_index, sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     p->read_end = read_end;
     return BASAL_OK;
 }
@@ -416,11 +479,13 @@ extern "C" int basal_pipe_stop(basal_pipe_t *p) {
 extern "C" int basal_pipe_rewind(basal_pipe_t *p) {
     if (!p) { set_error("pipe_rewind: null argument"); return BASAL_EINVAL; }
     std::lock_guard<std::mutex> lk(p->m);
-    HIP_TRYQ(hipSetDevice(p->c->device));
-    HIP_TRYQ(hipStreamSynchronize(p->st_in));
-    HIP_TRYQ(hipStreamSynchronize(p->st_comp));
-    HIP_TRYQ(hipStreamSynchronize(p->st_out));
-    HIP_TRYQ(hipStreamSynchronize(p->st_cnt));
+    for (auto &v : p->devs) {
+        HIP_TRYQ(hipSetDevice(v.c->device));
+        HIP_TRYQ(hipStreamSynchronize(v.st_in));
+        HIP_TRYQ(hipStreamSynchronize(v.st_comp));
+        HIP_TRYQ(hipStreamSynchronize(v.st_out));
+        HIP_TRYQ(hipStreamSynchronize(v.st_cnt));
+    }
     for (auto &s : p->slots) {
         s.state = ST_FREE;
         s.collecting = false;
@@ -428,6 +493,9 @@ extern "C" int basal_pipe_rewind(basal_pipe_t *p) {
     p->inflight.clear();
     p->acquired = p->held = -1;
     if (p->broken) p->next_batch = p->rewind_to;
+    // (the state batch rewind_to started from is where it was: on the GPU that prepared the batch before it; everything is idle now, so no
+    // event is pending for any state; the states of the dropped batches are simply written again)
+    for (auto &cs : p->carry_slot) cs = -1;
     p->broken = false;
     p->cv.notify_all();
     return BASAL_OK;
@@ -446,7 +514,6 @@ extern "C" int basal_pipe_release(basal_pipe_t *p) {
 
 extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *nbytes, basal_batch_stats *stats) {
     if (!p) { set_error("pipe_collect: null argument"); return BASAL_EINVAL; }
-    basal_core *c = p->c;
     int si;
     {
         std::lock_guard<std::mutex> lk(p->m);
@@ -461,6 +528,8 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
         p->slots[(size_t)si].collecting = true;
     }
     Slot &s = p->slots[(size_t)si];
+    PipeDev &v = p->devs[(size_t)s.dev];
+    basal_core *c = v.c;
     HIP_TRYQ(hipSetDevice(c->device));
     HIP_TRYQ(hipEventSynchronize(s.ev[EV_COUNTERS]));
     int ret = basal_report_guard(s.h_guard);
@@ -477,8 +546,8 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             const BatchCounters &cn = *s.h_cnt;
             const bool stream_small = d.stream && cn.stream_used > d.stream_cap, out_small = cn.out_bytes > d.out_cap;
             if (!stream_small && !out_small && !(cn.irregular & 2u)) break;
-            HIP_TRYQ(hipStreamSynchronize(p->st_comp));
-            HIP_TRYQ(hipStreamSynchronize(p->st_cnt));
+            HIP_TRYQ(hipStreamSynchronize(v.st_comp));
+            HIP_TRYQ(hipStreamSynchronize(v.st_cnt));
             if (stream_small || (cn.irregular & 2u)) {
                 hipFree(d.stream);
                 d.stream = nullptr;
@@ -495,14 +564,14 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             BatchCounters z = cn;
             z.n_aligned = z.n_unique = z.n_multiple = 0; z.out_bytes = 0; z.irregular &= ~2u;
             if (stream_small || (cn.irregular & 2u)) z.stream_used = 0;
-            HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, p->st_comp));
-            HIP_TRYQ(hipStreamSynchronize(p->st_comp));
+            HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, v.st_comp));
+            HIP_TRYQ(hipStreamSynchronize(v.st_comp));
             if (stream_small || (cn.irregular & 2u)) { int rc = queue_align(p, s); if (rc) return rc; }
-            { int rc = prep_enqueue_format(c, p->k, d, p->sh, p->o.max_reads, p->st_comp); if (rc) return rc; }
-            HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, p->st_comp));
-            HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, p->st_comp));
-            HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), p->st_comp));
-            HIP_TRYQ(hipStreamSynchronize(p->st_comp));
+            { int rc = prep_enqueue_format(c, p->k, d, v.sh, p->o.max_reads, v.st_comp); if (rc) return rc; }
+            HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, v.st_comp));
+            HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, v.st_comp));
+            HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), v.st_comp));
+            HIP_TRYQ(hipStreamSynchronize(v.st_comp));
             if ((ret = basal_report_guard(s.h_guard))) break;
         }
     }

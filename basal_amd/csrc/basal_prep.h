@@ -84,9 +84,9 @@ struct SlotDev {
 };
 
 struct PrepShared {  // per pipe, shared by the slots
-    // ring of carry states: batch b reads [b % ncarry], writes [(b + 1) % ncarry]; ncarry = depth + 1, so the state a batch started
+    // ring of carry states: batch b reads [b % ncarry], writes [(b + 1) % ncarry]; ncarry = batches in flight (depth x GPUs of the pipe) + 1, so the state a batch started
     // from survives until every batch that was in flight with it has been collected (a batch can be re-submitted from it)
-    CarryState *carry[10] = {nullptr};
+    CarryState *carry[129] = {nullptr};
     uint32_t ncarry = 0;
     const char *names = nullptr;                // contig names blob
     const uint32_t *name_off = nullptr;         // [ncontig + 1]

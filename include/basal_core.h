@@ -227,6 +227,11 @@ typedef struct basal_batch_stats { /* main.cpp:606-612 */
 } basal_batch_stats;
 
 int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basal_pipe_t **out);
+/* The same pipe over several GPUs (one staged core each; the same parameters, reference and index on all of them): whole batches fan out
+ * over the GPUs like the batches of the reference's worker threads (main.cpp:60-92, 154-166), `depth` in flight per GPU, each batch on one
+ * GPU from its text to its SAM bytes; the state a SingleAlign carries from read to read (align.cpp:475-480) follows the batch numbers from
+ * GPU to GPU, so the output is the one-GPU output. Every other basal_pipe_* call works on it unchanged. */
+int basal_pipe_create_multi(basal_core_t *const *cores, int ncores, const basal_pipe_opts *o, basal_pipe_t **out);
 void basal_pipe_destroy(basal_pipe_t *p);
 /* The next free batch slot's page-locked input buffers (blocks while all `depth` slots are in flight and uncollected).
  * blob: max_bytes bytes; raw: max_reads entries (used by submit_records only; may be ignored). */

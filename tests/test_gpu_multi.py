@@ -1,7 +1,10 @@
-"""The multi-GPU layer (basal_multi_*: reads sharded by read number, RCCL gather of the hit records to GPU 0) on the one GPU a test box
-has: one rank, so the collective degenerates, but every call of the sharded path runs -- ncclCommInitAll, the grouped ncclGather of
-records and hit streams, the stream-offset fix-up.  The sharding rule itself is covered for world sizes > 1 in tests/test_dist_gloo.py
-(CPU, same C function).  More ranks than GPUs cannot be rehearsed here: RCCL refuses a device listed twice."""
+"""The multi-GPU layers on the one GPU a test box has.
+* basal_pipe_create_multi (`basal -G a,b,...`, single-end): whole batches fan out over one core per GPU, the carry state follows the batch
+  numbers from GPU to GPU.  A GPU may be listed twice (two cores on one GPU), so the hand-over between ranks really runs here: `-G 0,0`.
+* basal_multi_* (paired-end with -G; reads sharded by read number, RCCL gather of the hit records to GPU 0): one rank, so the collective
+  degenerates, but every call of the sharded path runs -- ncclCommInitAll, the grouped ncclGather of records and hit streams, the
+  stream-offset fix-up.  The sharding rule itself is covered for world sizes > 1 in tests/test_dist_gloo.py (CPU, same C function); more
+  ranks than GPUs cannot be rehearsed for this layer: RCCL refuses a device listed twice."""
 import os
 import subprocess
 
@@ -45,15 +48,80 @@ def test_multi_align_batch_equals_core_align_batch(name, mode):
 
 @pytest.mark.parametrize("name", ["ct_basic", "varlen_trim", "rep_r2_w10", "tdel_pipeline", "pe_ct_100_u", "pe_rep_r2"])
 def test_cli_sharded_path_matches_golden(name, tmp_path):
-    """`basal -G 0,1,...` takes the sharded path (host QC and SAM text, basal_multi_align_batch); BASAL_FORCE_MULTI runs it on one GPU."""
+    """Paired-end `basal -G 0,1,...` and, with BASAL_MULTI_HOST, single-end too take the sharded path (host QC and SAM text,
+    basal_multi_align_batch); BASAL_FORCE_MULTI runs it on one GPU."""
     fa, fq, fq2, _ = H.fixture_paths(name)
     pe = H.MANIFEST[name]["pe"]
     out = tmp_path / "o.sam"
     r = subprocess.run([BASAL_BIN, "-a", fq] + (["-b", fq2] if pe else []) + ["-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "4", "-G", "0", "-Z", "300", "-o", str(out)],
-                       capture_output=True, text=True, env=dict(os.environ, BASAL_FORCE_MULTI="1"))
+                       capture_output=True, text=True, env=dict(os.environ, BASAL_FORCE_MULTI="1", BASAL_MULTI_HOST="1"))
     assert r.returncode == 0, r.stderr
     got = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+SE_TWO_RANKS = [n for n in H.SE if n.startswith(("varlen", "ct_basic", "rep_r2", "tdel", "acgt_g2", "long_", "dirty", "fasta_reads", "contigs_5k"))]
+
+
+@pytest.mark.parametrize("gpus,pipe_bytes", [("0,0", "8192"), ("0,0,0", "20000"), ("0,0", None)])
+@pytest.mark.parametrize("name", SE_TWO_RANKS)
+def test_cli_two_ranks_one_pipeline_matches_golden(name, gpus, pipe_bytes, tmp_path):
+    """`basal -G 0,0`: two (three) cores behind one batch pipeline, batches alternating between them -- with small batches the state a
+    SingleAlign carries from read to read (the varlen_* fixtures' inherited offsets and seed slots) crosses from rank to rank hundreds of
+    times, and the irregular-text fallback (fasta_reads, dirty reads) rewinds a pipe whose batches are spread over the ranks."""
+    assert len(SE_TWO_RANKS) >= 8
+    fa, fq, _, _ = H.fixture_paths(name)
+    out = tmp_path / "o.sam"
+    env = dict(os.environ)
+    if pipe_bytes:  # small batches of the uncompressed file: the GPU finds the records in the text (the .gz form is parsed on the host)
+        env["BASAL_PIPE_BYTES"] = pipe_bytes
+        import gzip
+        plain = tmp_path / os.path.basename(fq)[:-3]
+        plain.write_bytes(gzip.open(fq, "rb").read())
+        fq = str(plain)
+    r = subprocess.run([BASAL_BIN, "-a", fq, "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "4", "-G", gpus, "-o", str(out)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    got = "".join(l for l in open(out) if not l.startswith("@PG"))
+    assert got == H.golden_sam(name)
+
+
+def test_pipe_two_ranks_equals_one_rank():
+    """basal_pipe_create_multi through the ABI: the same text batches through a one-core pipe and through a pipe over two cores (same GPU
+    listed twice) give the same SAM bytes, batch by batch."""
+    name = "varlen_trim"
+    fa, fq, _, _ = H.fixture_paths(name)
+    flags = H.MANIFEST[name]["flags"]
+    p = B.Params(H.rule_of(flags), flags)
+    ref = B.Reference(p, fasta_path=fa)
+    ref.build_index(4)
+    cores = [B.Core(p), B.Core(p)]
+    for c in cores:
+        c.upload(ref)
+        c.set_contig_names(ref.names())
+    text = open(fq, "rb").read() if not fq.endswith(".gz") else __import__("gzip").open(fq, "rb").read()
+    lines = text.rstrip(b"\n").split(b"\n")
+    per = 4 * 23  # 23 reads per batch
+    batches = [b"\n".join(lines[i:i + per]) + b"\n" for i in range(0, len(lines), per)]
+    outs = []
+    for cs in (cores[0], cores):
+        pipe = B.Pipe(cs, depth=2, max_reads=4096, max_bytes=1 << 20)
+        got, inflight = [], 0
+        for b in batches:
+            if inflight == (2 if cs is cores[0] else 4):
+                rc, data, _ = pipe.collect()
+                assert rc == 0, data
+                got.append(data)
+                inflight -= 1
+            pipe.submit_text(b)
+            inflight += 1
+        while inflight:
+            rc, data, _ = pipe.collect()
+            assert rc == 0, data
+            got.append(data)
+            inflight -= 1
+        pipe.close()
+        outs.append(got)
+    assert len(outs[0]) == len(batches) and outs[0] == outs[1]
 
 
 def test_multi_refuses_a_device_twice():
