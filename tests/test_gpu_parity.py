@@ -347,3 +347,22 @@ def test_reference_host_on_gpu_core(name, tmp_path):
     assert r.returncode == 0, r.stderr
     got = "".join(l for l in open(tmp_path / "o.sam") if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+@pytest.mark.parametrize("name", [n for n in H.MANIFEST if H.MANIFEST[n]["pe"]])
+def test_reference_host_on_gpu_core_paired_end(name, tmp_path):
+    """The second caller of the boundary: the UNMODIFIED reference host in paired-end mode (t_PairAlign, main.cpp:95-122), with
+    PairAlign::Do_Batch from integration/pair_do_batch_gpu.inc on basal_core_align_pairs_batch and the reference's own FilterReads,
+    FixPairReadName, s_OutHitPair and s_OutHitUnpair.  Its SAM must be the golden SAM the pure-CPU reference printed."""
+    if not os.path.exists(REF_GPU_BIN):
+        pytest.skip("oracle/_ref_gpu/basal not built (tools/build_ref_with_core.sh needs /root/reference)")
+    import gzip
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    for src, dst in ((fa, "g.fa"), (fq, "r1.fq"), (fq2, "r2.fq")):
+        open(tmp_path / dst, "wb").write(gzip.open(src, "rb").read() if src.endswith(".gz") else open(src, "rb").read())
+    for threads in ("1", "3"):  # (-p 3: several PairAlign objects take turns on the one core; the fixtures fit one batch, so the order is the same)
+        r = subprocess.run([REF_GPU_BIN, "-a", "r1.fq", "-b", "r2.fq", "-d", "g.fa"] + H.MANIFEST[name]["flags"] + ["-p", threads, "-o", "o.sam"], capture_output=True, text=True,
+                           cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+        got = "".join(l for l in open(tmp_path / "o.sam") if not l.startswith("@PG"))
+        assert got == H.golden_sam(name), "-p " + threads
