@@ -1969,8 +1969,8 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
     HIP_TRY(hipMemcpy(c->d_tables, tabs, sizeof tabs, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&c->d_counter, 256 * sizeof(unsigned int)));  // [0] queue head, [1..24] guard ledger, [32..] phase clocks (diagnostic build)
     HIP_TRY(hipMemset(c->d_counter, 0, 256 * sizeof(unsigned int)));
-    HIP_TRY(hipMalloc(&c->d_used, sizeof(unsigned long long)));
-    HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipMalloc(&c->lane0.d_used, sizeof(unsigned long long)));
+    HIP_TRY(hipStreamCreate(&c->lane0.stream));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     c->total_kmers = pow3(p->seed_size);
@@ -1986,12 +1986,17 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_names); hipFree(c->d_name_off);
     hipFree(c->d_pe_pairs); hipFree(c->d_pe_recs); hipFree(c->d_pe_work); hipFree(c->d_pe_misc);
-    hipFree(c->d_counter); hipFree(c->d_bases); hipFree(c->d_reads); hipFree(c->d_stales); hipFree(c->d_results); hipFree(c->d_stream); hipFree(c->d_used);
+    hipFree(c->d_counter);
+    c->more_lanes.push_back(&c->lane0);
+    for (CoreLane *L : c->more_lanes) {
+        hipFree(L->d_bases); hipFree(L->d_reads); hipFree(L->d_stales); hipFree(L->d_results); hipFree(L->d_stream); hipFree(L->d_used); hipFree(L->d_counter); hipFree(L->d_scratch);
+        if (L->stream) hipStreamDestroy(L->stream);
+        if (L != &c->lane0) delete L;
+    }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev2) hipEventDestroy(c->ev2);
     if (c->ev3) hipEventDestroy(c->ev3);
-    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -2297,6 +2302,49 @@ static int grow(T *&p, size_t &cap, size_t need) {
     return BASAL_OK;
 }
 
+// A lane for one basal_core_align_batch call: lane 0 if it is free, else one of up to kMaxLanes - 1 more (made on first use: a stream,
+// a queue head + ledger, per-wave hit logs), else the call waits for one. The paired-end entry point always takes lane 0.
+struct LaneHold {
+    basal_core *c;
+    CoreLane *L = nullptr;
+    explicit LaneHold(basal_core *c_, bool lane0_only = false) : c(c_) {
+        std::unique_lock<std::mutex> lk(c->lane_m);
+        if (!c->grid && ensure_launch_geometry(c)) return;  // (sizes the per-wave hit logs; under the lock: the first calls may arrive together)
+        for (;;) {
+            if (!c->lane0.busy) { L = &c->lane0; break; }
+            if (!lane0_only) {
+                for (CoreLane *x : c->more_lanes) if (!x->busy) { L = x; break; }
+                if (L) break;
+                static const int max_lanes = getenv("BASAL_CORE_LANES") ? atoi(getenv("BASAL_CORE_LANES")) : kMaxLanes;
+                if ((int)c->more_lanes.size() + 1 < max_lanes) {
+                    CoreLane *x = new CoreLane();
+                    const size_t scratch = (size_t)c->grid * 4 * c->scratch_per_wave * sizeof(basal_hit);
+                    if (hipMalloc(&x->d_used, sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&x->stream) != hipSuccess ||
+                        hipMalloc(&x->d_counter, 256 * sizeof(unsigned int)) != hipSuccess || hipMemset(x->d_counter, 0, 256 * sizeof(unsigned int)) != hipSuccess ||
+                        hipMalloc(&x->d_scratch, scratch) != hipSuccess) {
+                        g_err = "align_batch: cannot set up another lane on this core";
+                        hipFree(x->d_used); hipFree(x->d_counter); hipFree(x->d_scratch);
+                        if (x->stream) hipStreamDestroy(x->stream);
+                        delete x;
+                        return;
+                    }
+                    c->more_lanes.push_back(x);
+                    L = x;
+                    break;
+                }
+            }
+            c->lane_cv.wait(lk);
+        }
+        L->busy = true;
+    }
+    ~LaneHold() {
+        if (!L) return;
+        std::lock_guard<std::mutex> lk(c->lane_m);
+        L->busy = false;
+        c->lane_cv.notify_all();
+    }
+};
+
 extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, const basal_stale *stales,
                                       uint32_t nstale, int stream_mode, basal_result *results, basal_hit *stream, uint64_t stream_cap,
                                       uint64_t *stream_used, uint8_t carry[2][2]) {
@@ -2307,34 +2355,41 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     if (n == 0) return BASAL_OK;
     uint32_t max_len = 0;
     if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_batch", &max_len)) return vrc;
+    LaneHold hold(c);  // a free lane (this call may run beside others on the same core); given back when the call returns
+    if (!hold.L) return BASAL_EDEVICE;
+    CoreLane &L = *hold.L;
+    basal_align_extra lane_ex;
+    const basal_align_extra *ex = nullptr;
+    unsigned int *ledger = c->d_counter;
+    if (&L != &c->lane0) { lane_ex.counter = L.d_counter; lane_ex.scratch = L.d_scratch; ex = &lane_ex; ledger = L.d_counter; }
     int rc;
-    size_t cap_res = c->cap_reads;
-    if ((rc = grow(c->d_bases, c->cap_bases, nbases + 64))) return rc;
-    if (n > c->cap_reads) {
-        hipFree(c->d_results);
-        c->d_results = nullptr;
+    size_t cap_res = L.cap_reads;
+    if ((rc = grow(L.d_bases, L.cap_bases, nbases + 64))) return rc;
+    if (n > L.cap_reads) {
+        hipFree(L.d_results);
+        L.d_results = nullptr;
     }
-    if ((rc = grow(c->d_reads, c->cap_reads, n))) return rc;
-    if (nstale && (rc = grow(c->d_stales, c->cap_stales, nstale))) return rc;
-    if (!c->d_results) HIP_TRY(hipMalloc(&c->d_results, c->cap_reads * sizeof(basal_result)));
+    if ((rc = grow(L.d_reads, L.cap_reads, n))) return rc;
+    if (nstale && (rc = grow(L.d_stales, L.cap_stales, nstale))) return rc;
+    if (!L.d_results) HIP_TRY(hipMalloc(&L.d_results, L.cap_reads * sizeof(basal_result)));
     (void)cap_res;
     if (stream_mode != BASAL_STREAM_NONE)
-        if ((rc = grow(c->d_stream, c->cap_stream, stream_cap ? stream_cap : 1))) return rc;
-    hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_bases, bases, nbases, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
-    if (nstale) HIP_TRY(hipMemcpyAsync(c->d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(c->d_used, 0, sizeof(unsigned long long), s));
+        if ((rc = grow(L.d_stream, L.cap_stream, stream_cap ? stream_cap : 1))) return rc;
+    hipStream_t s = L.stream;
+    HIP_TRY(hipMemcpyAsync(L.d_bases, bases, nbases, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(L.d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
+    if (nstale) HIP_TRY(hipMemcpyAsync(L.d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(L.d_used, 0, sizeof(unsigned long long), s));
     static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
-    rc = launch_align(c, c->d_bases, nbases, c->d_reads, n, nstale ? c->d_stales : nullptr, nstale, max_len, stream_mode, c->d_results, c->d_stream, stream_cap, c->d_used,
-                      carry ? (const uint8_t(*)[2])carry : zero_carry, s);
+    rc = launch_align(c, L.d_bases, nbases, L.d_reads, n, nstale ? L.d_stales : nullptr, nstale, max_len, stream_mode, L.d_results, L.d_stream, stream_cap, L.d_used,
+                      carry ? (const uint8_t(*)[2])carry : zero_carry, s, ex);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(results, c->d_results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(results, L.d_results, (size_t)n * sizeof(basal_result), hipMemcpyDeviceToHost, s));
     unsigned long long used = 0;
     unsigned int guard[24];
-    HIP_TRY(hipMemcpyAsync(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(guard, c->d_counter + 1, sizeof guard, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemsetAsync(c->d_counter + 1, 0, sizeof guard, s));
+    HIP_TRY(hipMemcpyAsync(&used, L.d_used, sizeof used, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(guard, ledger + 1, sizeof guard, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(ledger + 1, 0, sizeof guard, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (int gr = report_guard(guard)) return gr;
 
@@ -2343,7 +2398,7 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     if (stream_mode != BASAL_STREAM_NONE) {
         if (used > stream_cap) { g_err = "align_batch: hit stream too small; needed " + std::to_string(used); ret = BASAL_EOVERFLOW; }
         uint64_t ncopy = used < stream_cap ? used : stream_cap;
-        if (ncopy) HIP_TRY(hipMemcpy(stream, c->d_stream, ncopy * sizeof(basal_hit), hipMemcpyDeviceToHost));
+        if (ncopy) HIP_TRY(hipMemcpy(stream, L.d_stream, ncopy * sizeof(basal_hit), hipMemcpyDeviceToHost));
     }
     // carry: xseed_start_offset after the last read of each slot that defined it (align.cpp:475-480)
     if (carry) {
@@ -2378,32 +2433,34 @@ extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *base
     HIP_TRY(hipSetDevice(c->device));
     uint32_t max_len = 0;
     if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_pairs_batch", &max_len)) return vrc;
+    LaneHold hold(c, true);  // (the pairing buffers are the core's: one paired-end call at a time)
+    if (!hold.L) return BASAL_EDEVICE;
     if (max_len == 0) max_len = 1;
     int rc;
-    if ((rc = grow(c->d_bases, c->cap_bases, nbases + 64))) return rc;
-    if (n > c->cap_reads) { hipFree(c->d_results); c->d_results = nullptr; }
-    if ((rc = grow(c->d_reads, c->cap_reads, n))) return rc;
-    if (nstale && (rc = grow(c->d_stales, c->cap_stales, nstale))) return rc;
-    if (!c->d_results) HIP_TRY(hipMalloc(&c->d_results, c->cap_reads * sizeof(basal_result)));
+    if ((rc = grow(c->lane0.d_bases, c->lane0.cap_bases, nbases + 64))) return rc;
+    if (n > c->lane0.cap_reads) { hipFree(c->lane0.d_results); c->lane0.d_results = nullptr; }
+    if ((rc = grow(c->lane0.d_reads, c->lane0.cap_reads, n))) return rc;
+    if (nstale && (rc = grow(c->lane0.d_stales, c->lane0.cap_stales, nstale))) return rc;
+    if (!c->lane0.d_results) HIP_TRY(hipMalloc(&c->lane0.d_results, c->lane0.cap_reads * sizeof(basal_result)));
     if ((rc = grow(c->d_pe_pairs, c->cap_pe_pairs, npairs))) return rc;
     if ((rc = grow(c->d_pe_recs, c->cap_pe_recs, recs_cap ? recs_cap : 1))) return rc;
     if (!c->d_pe_misc) HIP_TRY(hipMalloc(&c->d_pe_misc, 16 * sizeof(unsigned long long)));
-    hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_bases, bases, nbases, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
-    if (nstale) HIP_TRY(hipMemcpyAsync(c->d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
+    hipStream_t s = c->lane0.stream;
+    HIP_TRY(hipMemcpyAsync(c->lane0.d_bases, bases, nbases, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->lane0.d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
+    if (nstale) HIP_TRY(hipMemcpyAsync(c->lane0.d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
     static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
     // the hit streams stay on the device: a first guess of their size, doubled until every mate's log fits
-    uint64_t stream_cap = c->cap_stream > (uint64_t)n * 8 + 4096 ? c->cap_stream : (uint64_t)n * 8 + 4096;
+    uint64_t stream_cap = c->lane0.cap_stream > (uint64_t)n * 8 + 4096 ? c->lane0.cap_stream : (uint64_t)n * 8 + 4096;
     unsigned long long used = 0;
     for (int attempt = 0;; attempt++) {
-        if ((rc = grow(c->d_stream, c->cap_stream, (size_t)stream_cap))) return rc;
+        if ((rc = grow(c->lane0.d_stream, c->lane0.cap_stream, (size_t)stream_cap))) return rc;
         if ((rc = grow(c->d_pe_work, c->cap_pe_work, (size_t)stream_cap))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_used, 0, sizeof(unsigned long long), s));
-        rc = launch_align(c, c->d_bases, nbases, c->d_reads, n, nstale ? c->d_stales : nullptr, nstale, max_len, BASAL_STREAM_ALL, c->d_results, c->d_stream, stream_cap, c->d_used,
+        HIP_TRY(hipMemsetAsync(c->lane0.d_used, 0, sizeof(unsigned long long), s));
+        rc = launch_align(c, c->lane0.d_bases, nbases, c->lane0.d_reads, n, nstale ? c->lane0.d_stales : nullptr, nstale, max_len, BASAL_STREAM_ALL, c->lane0.d_results, c->lane0.d_stream, stream_cap, c->lane0.d_used,
                           carry ? (const uint8_t(*)[2])carry : zero_carry, s);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&used, c->lane0.d_used, sizeof used, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (used <= stream_cap) break;
         if (attempt > 3) { g_err = "align_pairs_batch: hit stream keeps overflowing"; return BASAL_EOVERFLOW; }
@@ -2418,7 +2475,7 @@ extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *base
     }
     HIP_TRY(hipMemsetAsync(c->d_pe_misc, 0, 16 * sizeof(unsigned long long), s));
     if (c->timing) { if (!c->ev2) { HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3)); } HIP_TRY(hipEventRecord(c->ev2, s)); }
-    rc = basal_pe_enqueue(c, c->d_reads, c->d_results, c->d_stream, c->d_pe_work, npairs, c->d_pe_pairs, c->d_pe_recs, recs_cap, c->d_pe_misc, c->d_pe_misc + 1, s);
+    rc = basal_pe_enqueue(c, c->lane0.d_reads, c->lane0.d_results, c->lane0.d_stream, c->d_pe_work, npairs, c->d_pe_pairs, c->d_pe_recs, recs_cap, c->d_pe_misc, c->d_pe_misc + 1, s);
     if (rc) return rc;
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev3, s)); c->pair_timed = true; }
     unsigned long long misc[16];
@@ -2441,7 +2498,7 @@ extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *base
                 const uint32_t rs = r.readset & 0x7fu;
                 if (r.len == 0 || (rs == 2 ? 1 : 0) != slot) continue;
                 basal_result one;
-                HIP_TRY(hipMemcpy(&one, c->d_results + i, sizeof one, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(&one, c->lane0.d_results + i, sizeof one, hipMemcpyDeviceToHost));
                 if (one.status == BASAL_READ_SKIPPED) continue;
                 const bool f0 = (c->p.chains == 1) || ((c->p.chains <= 1) == (rs < 2)), f1 = (c->p.chains == 1) || ((c->p.chains <= 1) == (rs == 2));
                 if (f0) carry[slot][0] = one.start_off[0];

@@ -2,7 +2,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <vector>
+
 #include "../../include/basal_core.h"
+
+// the device-side staging of one basal_core_align_batch call in flight
+struct CoreLane {
+    uint8_t *d_bases = nullptr; size_t cap_bases = 0;
+    basal_read *d_reads = nullptr; size_t cap_reads = 0;
+    basal_stale *d_stales = nullptr; size_t cap_stales = 0;
+    basal_result *d_results = nullptr;
+    basal_hit *d_stream = nullptr; size_t cap_stream = 0;
+    unsigned long long *d_used = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned int *d_counter = nullptr;  // lanes 1..: their own queue head + guard ledger and per-wave hit logs (lane 0 uses the core's)
+    basal_hit *d_scratch = nullptr;
+    bool busy = false;
+};
+constexpr int kMaxLanes = 4;
 
 struct basal_core {
     basal_params p;
@@ -26,14 +45,13 @@ struct basal_core {
     unsigned int *d_counter = nullptr;  // [0] work queue head, [1..24] guard ledger
     uint32_t grid = 0, last_grid = 0;
     int nwt = 0;
-    // staging for the host-buffer entry point
-    uint8_t *d_bases = nullptr; size_t cap_bases = 0;
-    basal_read *d_reads = nullptr; size_t cap_reads = 0;
-    basal_stale *d_stales = nullptr; size_t cap_stales = 0;
-    basal_result *d_results = nullptr;
-    basal_hit *d_stream = nullptr; size_t cap_stream = 0;
-    unsigned long long *d_used = nullptr;
-    hipStream_t stream = nullptr, last_stream = nullptr;
+    // staging for the host-buffer entry points: lane 0 (also the paired-end entry point's); more lanes appear when several host threads call
+    // basal_core_align_batch at once (the reference runs one SingleAlign per worker thread, main.cpp:60-92): each call takes a free lane
+    CoreLane lane0;
+    std::vector<CoreLane *> more_lanes;  // lazily created, at most kMaxLanes - 1
+    std::mutex lane_m;
+    std::condition_variable lane_cv;
+    hipStream_t last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // around the align launch; around the pairing kernel
     bool timing = false, timed = false, pair_timed = false;
     // paired-end pairing on the device (basal_pe.hip)

@@ -219,3 +219,33 @@ def test_cli_pe_100k_contigs_device_pairing_equals_host_replay(tmp_path):
         outs.append(sam_digest(out))
     assert outs[0][1] >= 2 * n * 0.9
     assert outs[0] == outs[1]
+
+
+def test_reference_host_worker_threads_share_one_core(tmp_path):
+    """The unmodified reference host on the core with -p 8 (oracle/_ref_gpu/basal): eight SingleAlign objects call basal_core_align_batch on
+    ONE core at the same time (each call takes a lane of the core: its own stream, staging and hit logs).  600 000 dirty, variable-length
+    reads = 12 batches of the reference's 50 000: with -p 8 the batches come out in any order and a read's inherited state depends on which
+    worker had the batch before (as in the reference itself), so the comparison is per read name against -p 1 of the same binary for every
+    read whose seeds cannot inherit anything ((len - I + 1) % k != 0), and the record count for all."""
+    ref_gpu = os.path.join(H.ROOT, "oracle", "_ref_gpu", "basal")
+    if not os.path.exists(ref_gpu):
+        pytest.skip("oracle/_ref_gpu/basal not built (tools/build_ref_with_core.sh needs /root/reference)")
+    fa, fq = make_files(str(tmp_path), "C:T", 600_000, 100, seed=61, min_len=60)
+    outs = {}
+    for threads in ("1", "8"):
+        r = subprocess.run([ref_gpu, "-a", "r.fq", "-d", "g.fa", "-M", "C:T", "-S", "1", "-s", "12", "-u", "-p", threads, "-o", "o%s.sam" % threads], capture_output=True, text=True,
+                           cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+        recs = {}
+        for line in open(tmp_path / ("o%s.sam" % threads)):
+            if not line.startswith("@"):
+                recs[line.split("\t", 1)[0]] = line
+        outs[threads] = recs
+    assert len(outs["1"]) == len(outs["8"]) == 600_000
+    same = plain = 0
+    for name, line in outs["1"].items():
+        seqlen = len(line.split("\t")[9])
+        if (seqlen - 4 + 1) % 12 != 0:  # -I 4, -s 12: this read computes its own start offset
+            plain += 1
+            same += outs["8"][name] == line
+    assert plain > 400_000 and same == plain
