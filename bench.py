@@ -197,6 +197,86 @@ def bench_pairs(args):
            "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "align_kernel<8,false,false> + pair_kernel",
                         "kernel_ms": float(np.mean(kms) + np.mean(pms))},
            "cpu_baseline": None}
+    # ---- parity + algorithmic bytes on a bounded sample, through files: the product's command line and the CPU oracle's on the same FASTA
+    # and FASTQ pair (the oracle restates pairs.cpp; its counters are SURVEY 8d's, summed over both mates) -- then the TRUE reference binary,
+    # timed on a 5 000-contig reference of the same kind (it clears one std::set per contig and read, align.cpp:437-444: 100 000 contigs
+    # would take it hours).
+    if args.cpu_sample > 0:
+        import hashlib
+        import re
+        import shutil
+        import subprocess
+        import tempfile
+        import synth_files
+        import oracle as orc
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        ns = max(2000, min(args.cpu_sample // 20, 20000))
+        d = tempfile.mkdtemp(prefix="basal_c3_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+
+        def digest(path):
+            h, n = hashlib.md5(), 0
+            for line in open(path, "rb"):
+                if not line.startswith(b"@PG"):
+                    h.update(line)
+                    n += not line.startswith(b"@")
+            return h.hexdigest(), n
+
+        def write_pairs(G_, n_, seed_):
+            b1, b2 = synth_gpu.make_pairs(G_, n_, dev, read_len=rl, seed=seed_)
+            for nm, b in (("r1.fq", b1), ("r2.fq", b2)):
+                open(os.path.join(d, nm), "wb").write(synth_files.fastq_bytes(b.cpu().numpy().reshape(n_, rl), np.full(n_, rl), None, name_prefix=b"p"))
+        try:
+            synth_files.write_fasta(os.path.join(d, "g.fa"), G)
+            write_pairs(G, ns, 77)
+            fl = ["-M", "A:G", "-S", "1", "-x", "700"]
+            r1 = subprocess.run([os.path.join(ROOT, "basal_amd", "bin", "basal"), "-a", "r1.fq", "-b", "r2.fq", "-d", "g.fa"] + fl + ["-p", str(threads), "-o", "gpu.sam"],
+                                capture_output=True, text=True, cwd=d)
+            r2 = subprocess.run([orc.CLI, "-a", "r1.fq", "-b", "r2.fq", "-d", "g.fa"] + fl + ["-p", str(threads), "-o", "cpu.sam"], capture_output=True, text=True, cwd=d)
+            if r1.returncode or r2.returncode:
+                raise SystemExit("bench --config 3: sample run failed: %s %s" % (r1.stderr[-300:], r2.stderr[-300:]))
+            # (-p N: the oracle's worker threads write whole batches in any order; the sample is below one batch of 50 000 pairs)
+            if digest(os.path.join(d, "gpu.sam")) != digest(os.path.join(d, "cpu.sam")):
+                raise SystemExit("bench --config 3: the SAM of %d sampled pairs differs between the GPU path and the CPU oracle -- number withheld" % ns)
+            m = re.search(r"ORACLE_COUNTERS reads (\d+) H (\d+) S (\d+) C (\d+) W (\d+) L (\d+) R (\d+)", r2.stderr)
+            secs = float(re.search(r"ORACLE_ALIGN_SECONDS ([0-9.]+)", r2.stderr).group(1))
+            _, H_, S_, C_, W_, L_, R_ = (int(x) for x in m.groups())
+            Bpair = (4 * H_ + 16 * S_ + 4 * C_ + 8 * W_ + L_ + 16 * R_) / ns
+            kms_all = float(np.mean(kms) + np.mean(pms))
+            ach = Bpair * npairs / (kms_all * 1e-3) / 1e9
+            out["config"]["algorithmic_bytes_per_pair"] = round(Bpair, 1)
+            out["config"]["counters_per_pair"] = {"H": H_ / ns, "S": S_ / ns, "C": C_ / ns, "W": W_ / ns, "L": L_ / ns, "R": R_ / ns}
+            out["roofline"].update({"achieved": ach, "frac": ach / 8000.0, "bytes_per_launch": Bpair * npairs})
+            port = {"value": ns / secs / 1e6, "unit": "Mpairs/s", "cores": threads, "kind": "port",
+                    "sample": "%d pairs of the timed kind on the same reference, through files; the command line's SAM identical to the oracle's on all of them" % ns}
+            out["cpu_baseline"] = port
+            ref_bin = os.path.join(ROOT, "oracle", "_ref", "basal")
+            if os.path.exists(ref_bin) and args.ref_sample > 0:
+                G5 = synth_gpu.make_transcriptome(params, dev, n_contigs=5000, seed=1)
+                synth_files.write_fasta(os.path.join(d, "g.fa"), G5)
+                nref = 100_000
+                write_pairs(G5, nref, 78)
+                cmd = [ref_bin, "-a", "r1.fq", "-b", "r2.fq", "-d", "g.fa"] + fl + ["-p", str(threads), "-o", "ref.sam"]
+
+                def wall(extra):
+                    t = time.perf_counter()
+                    if subprocess.run(cmd + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d).returncode != 0:
+                        raise RuntimeError("reference binary failed")
+                    return time.perf_counter() - t
+                t_idle = min(wall(["-E", "0"]) for _ in range(2))
+                t_full = wall([])
+                out["config"]["cpu_port"] = port
+                out["cpu_baseline"] = {"value": nref / max(t_full - t_idle, 1e-3) / 1e6, "unit": "Mpairs/s", "cores": threads, "kind": "reference",
+                                       "sample": "the unmodified reference binary (oracle/_ref/basal -p %d) on %d pairs of the same kind on a 5 000-contig transcriptome stand-in "
+                                                 "(it clears one std::set per contig and read: 100 000 contigs are out of its reach); align time = wall %.2f s minus %.2f s of "
+                                                 "the same command with -E 0" % (threads, nref, t_full, t_idle)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        t = json.load(open(tj)).get("other_workloads", {}).get("config3")
+        if t:
+            out["roofline"]["traffic"] = t["hbm_bytes_per_pair"] * npairs
+            out["roofline"]["traffic_source"] = t["source"]
     print(json.dumps(out))
 
 
