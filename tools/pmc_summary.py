@@ -12,7 +12,7 @@ reads = 1_000_000
 for j in glob.glob(os.path.join(out, "*.json")):
     try:
         d = json.loads(open(j).read().strip().splitlines()[-1])
-        reads = d["config"]["reads_per_step_per_gpu"]
+        reads = d["config"].get("reads_per_step_per_gpu") or d["config"]["pairs_per_step"]  # (config 3: per read pair)
         break
     except Exception:
         pass
