@@ -69,12 +69,12 @@ class basal_rawread(C.Structure):
 
 
 class basal_pipe_opts(C.Structure):
-    _fields_ = [("depth", C.c_uint32), ("max_reads", C.c_uint32), ("max_bytes", C.c_uint64), ("output", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("depth", C.c_uint32), ("max_reads", C.c_uint32), ("max_bytes", C.c_uint64), ("output", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class basal_batch_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_reads", "n_aligned", "n_unique", "n_multiple", "n_filtered")] + [
-        (n, C.c_float) for n in ("ms_h2d", "ms_prep", "ms_align", "ms_format", "ms_d2h")]
+        (n, C.c_float) for n in ("ms_h2d", "ms_prep", "ms_align", "ms_format", "ms_d2h")] + [("pe", C.c_uint32 * 9), ("pad", C.c_uint32)]
 
 
 PIPE_OUT_SAM, PIPE_OUT_RESULTS = 0, 1
@@ -116,6 +116,7 @@ SYMBOLS = [
     ("basal_last_error", C.c_char_p, []),
     ("basal_core_set_contig_names", _i, [_vp, _P(C.c_char_p), _u32]),
     ("basal_pipe_create", _i, [_vp, _P(basal_pipe_opts), _P(_vp)]),
+    ("basal_pipe_submit_text_pairs", _i, [_vp, _u64, _u64, _u32, _i, _u32]),
     ("basal_pipe_create_multi", _i, [_P(_vp), _i, _P(basal_pipe_opts), _P(_vp)]),
     ("basal_pipe_destroy", None, [_vp]),
     ("basal_pipe_acquire", _i, [_vp, _P(_vp), _P(_vp)]),
@@ -386,13 +387,13 @@ class Core:
 class Pipe:
     """basal_pipe_t: batches of raw read text / raw read tables / prepared reads in, SAM text / basal_result records out."""
 
-    def __init__(self, core, depth=3, max_reads=1 << 16, max_bytes=32 << 20, output=PIPE_OUT_SAM):
+    def __init__(self, core, depth=3, max_reads=1 << 16, max_bytes=32 << 20, output=PIPE_OUT_SAM, pairs=False):
         """core: one Core, or a list of Cores (one per GPU, all staged alike): batches then fan out over them (basal_pipe_create_multi)."""
         self.core = core
         self.h = C.c_void_p()
         self.max_reads = (max_reads + 4095) & ~4095
         self.max_bytes = (max_bytes + 4095) & ~4095
-        o = basal_pipe_opts(depth, max_reads, max_bytes, output, 0)
+        o = basal_pipe_opts(depth, max_reads, max_bytes, output, 1 if pairs else 0)
         if isinstance(core, (list, tuple)):
             arr = (C.c_void_p * len(core))(*[c.h for c in core])
             _check(lib().basal_pipe_create_multi(arr, len(core), C.byref(o), C.byref(self.h)), "pipe_create_multi")

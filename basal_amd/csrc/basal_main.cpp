@@ -815,6 +815,334 @@ struct BatchQueue {
     }
 };
 
+// =========================================================================== paired-end through the device-side pipeline (one GPU)
+// number of '\n' among the n bytes at p
+inline size_t count_newlines(const char *p, size_t n) {
+    size_t c = 0, i = 0;
+#if defined(__SSE2__)
+    const __m128i nl = _mm_set1_epi8('\n');
+    for (; i + 16 <= n; i += 16) c += (size_t)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nl)));
+#endif
+    for (; i < n; i++) c += p[i] == '\n';
+    return c;
+}
+// bytes up to and including the k-th '\n' (k >= 1) among the n bytes at p; 0 if there are fewer
+inline size_t bytes_of_lines(const char *p, size_t n, size_t k) {
+    size_t c = 0, i = 0;
+#if defined(__SSE2__)
+    const __m128i nl = _mm_set1_epi8('\n');
+    for (; i + 16 <= n; i += 16) {
+        const unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nl));
+        const size_t here = (size_t)__builtin_popcount(m);
+        if (c + here >= k) break;
+        c += here;
+    }
+#endif
+    for (; i < n; i++)
+        if (p[i] == '\n' && ++c == k) return i + 1;
+    return 0;
+}
+
+// Paired-end: FilterReads x 2, FixPairReadName, the mates' alignment, the pairing rounds and the text of s_OutHitPair / s_OutHitUnpair
+// (pairs.cpp:179-507) all run on the GPU (basal_pipe_* with BASAL_PIPE_PAIRS); the host only cuts and writes. Plain FASTQ / FASTA mate files go
+// to the GPU as text: mate 1's records of a batch, then the same number of mate 2's (the host counts newlines; the device finds the records
+// and refuses a text whose lines and the reference's token reader would disagree on -- the run then continues in the second form from that
+// batch's first bytes). Everything else (gz, BAM, irregular text) is parsed by two reader threads and handed over as a table of records.
+void run_pe_pipe(Cli &cli, basal_pipe_t *pipe, const basal_pipe_opts &po, Output &out, uint32_t pst[9], uint64_t &n_pairs, double &t_gpu) {
+    basal_params &P = cli.P;
+    const int threads = cli.threads;
+    bool plain = !getenv("BASAL_HOST_PARSE");
+    bool fastq = true;
+    if (plain) {
+        int lead[2] = {0, 0};
+        const std::string *paths[2] = {&cli.qa, &cli.qb};
+        for (int m = 0; m < 2 && plain; m++) {
+            FILE *f = fopen(paths[m]->c_str(), "rb");
+            if (!f) die(std::string(m ? "failed to open read file #2 (check -b option): " : "failed to open read file (check -a option): ") + *paths[m]);
+            struct stat sb;
+            lead[m] = fgetc(f);
+            plain = fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) && (lead[m] == '@' || lead[m] == '>');
+            fclose(f);
+        }
+        plain = plain && lead[0] == lead[1];
+        fastq = lead[0] == '@';
+    }
+    struct BatchInfo { uint64_t off_a, off_b; uint32_t first_index; };
+    std::mutex qm;
+    std::deque<BatchInfo> submitted;
+    std::atomic<bool> producer_done{false}, stop{false};
+    std::string producer_err;
+
+    auto producer_text = [&]() {
+        int fd[2] = {open(cli.qa.c_str(), O_RDONLY), open(cli.qb.c_str(), O_RDONLY)};
+        if (fd[0] < 0 || fd[1] < 0) { producer_err = "failed to open the read files"; producer_done = true; return; }
+        uint64_t fsize[2], off[2] = {0, 0};
+        for (int m = 0; m < 2; m++) { struct stat sb; fstat(fd[m], &sb); fsize[m] = (uint64_t)sb.st_size; }
+        if (cli.read_start > 1)  // -B: skip the lines of the pairs before read_start (a prefix of both files)
+            for (int m = 0; m < 2; m++) {
+                Reader r;
+                if (!r.open(m ? cli.qb.c_str() : cli.qa.c_str())) { producer_err = "failed to open read file"; producer_done = true; return; }
+                skip_reads(r, P, cli.read_start, 1);
+                off[m] = (uint64_t)gztell(r.f) - (r.end - r.pos);
+                r.close();
+            }
+        const size_t lpr = fastq ? 4 : 2;
+        uint32_t index = cli.read_start - 1;
+        double est[2] = {2.0 * P.max_readlen + 64, 2.0 * P.max_readlen + 64};  // bytes per record of either file: from the batch before (first: generous)
+        const int rthreads = std::max(1, std::min(threads, 8));
+        auto pread_all = [&](int f, uint8_t *dst, size_t n, uint64_t at) {
+            if (n > (8u << 20) && rthreads > 1) {  // the page cache gives a few GB/s per core
+                std::vector<std::thread> th;
+                std::atomic<bool> bad{false};
+                for (int t = 0; t < rthreads; t++)
+                    th.emplace_back([&, t] {
+                        size_t b = n * (size_t)t / (size_t)rthreads, e = n * (size_t)(t + 1) / (size_t)rthreads;
+                        while (b < e) {
+                            ssize_t g = pread(f, dst + b, e - b, (off_t)(at + b));
+                            if (g <= 0) { bad = true; return; }
+                            b += (size_t)g;
+                        }
+                    });
+                for (auto &t : th) t.join();
+                return !bad.load();
+            }
+            size_t b = 0;
+            while (b < n) {
+                ssize_t g = pread(f, dst + b, n - b, (off_t)(at + b));
+                if (g <= 0) return false;
+                b += (size_t)g;
+            }
+            return true;
+        };
+        while (!stop) {
+            if (off[0] >= fsize[0] || off[1] >= fsize[1] || index >= cli.read_end) break;
+            uint8_t *blob = nullptr;
+            basal_rawread *raw = nullptr;
+            if (basal_pipe_acquire(pipe, &blob, &raw)) break;  // the pipe was stopped (a batch was refused)
+            if (stop) { basal_pipe_cancel(pipe); break; }
+            // mate 1: the batch's records out of a window sized from the records seen so far (at most half the buffer)
+            const size_t want_pairs = std::min<size_t>(po.max_reads / 2, (size_t)(cli.read_end - index));
+            size_t have_a = (size_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)(want_pairs * est[0] * 1.03) + (64u << 10), (po.max_bytes - 4096) / 2), fsize[0] - off[0]);
+            if (!pread_all(fd[0], blob, have_a, off[0])) { producer_err = "read failed on " + cli.qa; basal_pipe_cancel(pipe); break; }
+            size_t file_a = have_a;
+            if (off[0] + have_a >= fsize[0] && blob[have_a - 1] != '\n') blob[have_a++] = '\n';  // a last line without a newline
+            size_t np = want_pairs;
+            size_t keep_a = bytes_of_lines((const char *)blob, have_a, np * lpr);
+            if (!keep_a) {  // the window holds fewer records than asked for (the end of the file, or longer records than estimated): take what it holds
+                np = count_newlines((const char *)blob, have_a) / lpr;
+                keep_a = np ? bytes_of_lines((const char *)blob, have_a, np * lpr) : 0;
+            }
+            // mate 2: the same number of records, right behind
+            size_t have_b = 0, keep_b = 0, file_b = 0;
+            bool eof_b = false;
+            if (np) {
+                have_b = (size_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)(np * est[1] * 1.03) + (64u << 10), po.max_bytes - keep_a - 1), fsize[1] - off[1]);
+                if (!pread_all(fd[1], blob + keep_a, have_b, off[1])) { producer_err = "read failed on " + cli.qb; basal_pipe_cancel(pipe); break; }
+                file_b = have_b;
+                eof_b = off[1] + have_b >= fsize[1];
+                if (eof_b && blob[keep_a + have_b - 1] != '\n') blob[keep_a + have_b++] = '\n';
+                keep_b = bytes_of_lines((const char *)blob + keep_a, have_b, np * lpr);
+                if (!keep_b && !eof_b) {  // mate 2's window was too small for these records: fewer pairs this time, a better estimate next time
+                    const size_t nb = count_newlines((const char *)blob + keep_a, have_b) / lpr;
+                    if (nb) {
+                        const size_t old_a = keep_a;
+                        np = nb;
+                        keep_a = bytes_of_lines((const char *)blob, have_a, np * lpr);
+                        keep_b = bytes_of_lines((const char *)blob + old_a, have_b, np * lpr);
+                        memmove(blob + keep_a, blob + old_a, keep_b);
+                    }
+                }
+            }
+            if (np && keep_a && keep_b) { est[0] = std::max(64.0, (double)keep_a / (double)np); est[1] = std::max(64.0, (double)keep_b / (double)np) * (keep_b ? 1.0 : 2.0); }
+            else if (np && !eof_b) est[1] *= 2;
+            if (!np || !keep_a || !keep_b) {
+                basal_pipe_cancel(pipe);
+                if (np && eof_b) {  // mate 2's file ends inside this batch: the reference stops at the batch whose two halves differ in size (main.cpp:105)
+                    if (cli.verbose >= 1) fprintf(stderr, "[BASAL-MI355X] warning: the mate files do not hold the same number of reads; stopping at read pair %u\n", index);
+                    break;
+                }
+                // no whole record in a whole window: not something the text path can take -- hand over to the host parser from here
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.push_back({off[0], off[1], index});
+                producer_err = "FALLBACK";
+                break;
+            }
+            {
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.push_back({off[0], off[1], index});
+            }
+            if (basal_pipe_submit_text_pairs(pipe, keep_a + keep_b, keep_a, (uint32_t)np, fastq ? BASAL_FMT_FASTQ : BASAL_FMT_FASTA, index)) {
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.pop_back();
+                break;
+            }
+            off[0] += std::min(keep_a, file_a);  // (an appended newline is not in the file)
+            off[1] += std::min(keep_b, file_b);
+            index += (uint32_t)np;
+        }
+        ::close(fd[0]);
+        ::close(fd[1]);
+        producer_done = true;
+    };
+
+    auto producer_records = [&](uint64_t off_a, uint64_t off_b, uint32_t first_index, bool skip_to_start) {
+        Reader ra, rb;
+        if (!ra.open(cli.qa.c_str(), off_a)) { producer_err = "failed to open read file (check -a option): " + cli.qa; producer_done = true; return; }
+        if (!rb.open(cli.qb.c_str(), off_b)) { producer_err = "failed to open read file #2 (check -b option): " + cli.qb; producer_done = true; return; }
+        if (skip_to_start) { skip_reads(ra, P, cli.read_start, 1); skip_reads(rb, P, cli.read_start, 1); }
+        else ra.index = rb.index = first_index;
+        BatchQueue<std::vector<Rec>> qa, qb, qfree;
+        qfree.cap = 8;
+        auto recycled = [&](std::vector<Rec> &v) {
+            std::lock_guard<std::mutex> l(qfree.m);
+            if (qfree.q.empty()) return;
+            v = std::move(qfree.q.front());
+            qfree.q.pop_front();
+        };
+        const size_t per = po.max_reads / 2;  // pairs per batch
+        // (reads are cut to max_readlen as they are parsed: two records of a pair stay below max_bytes / per together)
+        std::thread ta([&] {
+            while (!stop.load()) {
+                std::vector<Rec> v;
+                recycled(v);
+                if (!load_batch(ra, P, cli.read_end, per, 1, v)) break;
+                qa.push(std::move(v));
+            }
+            qa.close();
+        });
+        std::thread tb([&] {
+            while (!stop.load()) {
+                std::vector<Rec> v;
+                recycled(v);
+                load_batch(rb, P, cli.read_end, per, 2, v);
+                if (v.empty()) break;
+                const bool short_file = v.size() != per;
+                qb.push(std::move(v));
+                if (short_file) break;
+            }
+            qb.close();
+        });
+        std::vector<Rec> ra_, rb_;
+        std::vector<size_t> off;
+        while (!stop) {
+            if (!ra_.empty()) qfree.try_push(std::move(ra_));
+            if (!rb_.empty()) qfree.try_push(std::move(rb_));
+            ra_.clear(); rb_.clear();
+            const bool ga = qa.pop(ra_), gb = ga && qb.pop(rb_);
+            if (!ga || !gb || ra_.empty()) break;
+            if (ra_.size() != rb_.size()) {  // the reference stops at the batch whose two halves differ in size (main.cpp:105)
+                if (cli.verbose >= 1) fprintf(stderr, "[BASAL-MI355X] warning: the mate files do not hold the same number of reads; stopping at read pair %u\n", ra_[0].index);
+                break;
+            }
+            const size_t np = ra_.size();
+            uint8_t *blob = nullptr;
+            basal_rawread *raw = nullptr;
+            if (basal_pipe_acquire(pipe, &blob, &raw)) break;
+            if (stop) { basal_pipe_cancel(pipe); break; }
+            off.resize(np + 1);
+            off[0] = 0;
+            for (size_t i = 0; i < np; i++) {
+                const Rec &x = ra_[i], &y = rb_[i];
+                off[i + 1] = off[i] + std::min<size_t>(x.name.size(), 0xffff) + strlen(x.seq.data()) + (x.has_qual ? strlen(x.qual.data()) : 0) +
+                             std::min<size_t>(y.name.size(), 0xffff) + strlen(y.seq.data()) + (y.has_qual ? strlen(y.qual.data()) : 0);
+            }
+            if (off[np] > po.max_bytes || 2 * np > po.max_reads) { producer_err = "paired-end batch larger than the pipeline's buffers"; basal_pipe_cancel(pipe); break; }
+            parallel_for(np, threads, [&](size_t b, size_t e, int) {
+                for (size_t i = b; i < e; i++) {
+                    size_t nb = off[i];
+                    for (int m = 0; m < 2; m++) {
+                        const Rec &rec = m ? rb_[i] : ra_[i];
+                        basal_rawread &w = raw[2 * i + m];
+                        memset(&w, 0, sizeof w);
+                        const size_t sl = strlen(rec.seq.data()), ql = rec.has_qual ? strlen(rec.qual.data()) : 0;
+                        w.name_off = (uint32_t)nb; w.name_len = (uint16_t)std::min<size_t>(rec.name.size(), 0xffff);
+                        memcpy(blob + nb, rec.name.data(), w.name_len); nb += w.name_len;
+                        w.seq_off = (uint32_t)nb; w.seq_len = (uint16_t)sl;
+                        memcpy(blob + nb, rec.seq.data(), sl); nb += sl;
+                        w.qual_off = (uint32_t)nb; w.qual_len = (uint16_t)ql;
+                        memcpy(blob + nb, rec.qual.data(), ql); nb += ql;
+                        w.readset = (uint8_t)(m ? 2 : 1); w.index = rec.index;
+                    }
+                }
+            });
+            {
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.push_back({0, 0, 0});
+            }
+            if (basal_pipe_submit_records(pipe, off[np], (uint32_t)(2 * np))) {
+                std::lock_guard<std::mutex> lk(qm);
+                submitted.pop_back();
+                break;
+            }
+        }
+        stop.store(true);
+        qa.close(); qb.close(); qfree.close();
+        ta.join();
+        tb.join();
+        producer_done = true;
+    };
+
+    std::thread pt;
+    if (plain) pt = std::thread(producer_text);
+    else pt = std::thread(producer_records, (uint64_t)0, (uint64_t)0, 0u, true);
+    double t_wait = 0, ms[5] = {0, 0, 0, 0, 0};
+    for (;;) {
+        const void *data = nullptr;
+        uint64_t nbytes = 0;
+        basal_batch_stats bs;
+        const double w0 = now();
+        int rc = basal_pipe_collect(pipe, &data, &nbytes, &bs);
+        t_wait += now() - w0;
+        bool fall_back = false;
+        if (rc == BASAL_ESTATE) {  // nothing in flight
+            if (producer_done) {
+                rc = basal_pipe_collect(pipe, &data, &nbytes, &bs);  // (the producer may have submitted its last batch between our collect and this test)
+                if (rc == BASAL_ESTATE) {
+                    if (plain && producer_err == "FALLBACK") fall_back = true;
+                    else break;
+                }
+            } else { std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }
+        }
+        if ((rc == BASAL_EIO && plain) || fall_back) {
+            // irregular text: stop the producer, drop what is in flight, go on with the host's parser from this batch's first bytes
+            stop = true;
+            basal_pipe_stop(pipe);
+            pt.join();
+            BatchInfo bi{0, 0, 0};
+            {
+                std::lock_guard<std::mutex> lk(qm);
+                if (!submitted.empty()) bi = submitted.front();
+                submitted.clear();
+            }
+            if (basal_pipe_rewind(pipe)) die(basal_last_error());
+            if (cli.verbose >= 1)
+                fprintf(stderr, "[BASAL-MI355X] mate files are not 4 regular lines per read from read pair %u on: parsing them on the host\n", bi.first_index);
+            plain = false;
+            stop = false;
+            producer_done = false;
+            producer_err.clear();
+            pt = std::thread(producer_records, bi.off_a, bi.off_b, bi.first_index, false);
+            continue;
+        }
+        if (rc) die(std::string("pipeline: ") + basal_last_error());
+        {
+            std::lock_guard<std::mutex> lk(qm);
+            if (!submitted.empty()) submitted.pop_front();
+        }
+        out.write((const char *)data, (size_t)nbytes);
+        for (int k = 0; k < 9; k++) pst[k] += bs.pe[k];
+        n_pairs += bs.n_reads / 2;
+        t_gpu += (bs.ms_prep + bs.ms_align + bs.ms_format) * 1e-3;
+        ms[0] += bs.ms_h2d; ms[1] += bs.ms_prep; ms[2] += bs.ms_align; ms[3] += bs.ms_format; ms[4] += bs.ms_d2h;
+        if (cli.verbose >= 2) fprintf(stderr, "[BASAL-MI355X] %llu read pairs finished.\n", (unsigned long long)n_pairs);
+    }
+    pt.join();
+    if (!producer_err.empty() && producer_err != "FALLBACK") die(producer_err);
+    if (cli.verbose >= 1)
+        fprintf(stderr, "\tGPU stage sums: H2D %.3f, read prep %.3f, align %.3f, pairing + SAM %.3f, D2H %.3f s; host side: waiting for results %.3f s\n", ms[0] / 1e3, ms[1] / 1e3,
+                ms[2] / 1e3, ms[3] / 1e3, ms[4] / 1e3, t_wait);
+}
+
 void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9], uint64_t &n_pairs, double &t_gpu) {
     basal_params &P = cli.P;
     const int threads = cli.threads;
@@ -1166,11 +1494,27 @@ int main(int argc, char **argv) {
     std::thread pipe_thread;
     std::string pipe_err;
     double t_pipe = 0;
+    // paired-end on one GPU: the same pipeline in its paired-end mode (records in, the pairs' SAM text out); BASAL_PE_HOST_PAIRING /
+    // BASAL_PE_NO_PIPE keep round 2's path (device or host pairing, text on the host) as the cross-check
+    const bool pe_pipe = P.pairend && !multi && !getenv("BASAL_PE_HOST_PAIRING") && !getenv("BASAL_PE_NO_PIPE");
     if (!P.pairend && !multi) {
         plan = plan_se(cli);
         pipe_thread = std::thread([&] {
             const double a0 = now();
             if (basal_pipe_create_multi(cores.data(), (int)cores.size(), &plan.po, &pipe)) pipe_err = basal_last_error();
+            t_pipe = now() - a0;
+        });
+    } else if (pe_pipe) {
+        memset(&plan.po, 0, sizeof plan.po);
+        const size_t pairs_per_batch = cli.batch ? std::max<size_t>(cli.batch / 2, 1) : (1u << 17);  // 131 072 pairs: the stages overlap from the first second on
+        plan.po.depth = 3;
+        plan.po.max_reads = (uint32_t)((2 * pairs_per_batch + 4095) & ~(size_t)4095);
+        plan.po.max_bytes = std::min<uint64_t>((uint64_t)plan.po.max_reads * (2ull * P.max_readlen + 300) + (1u << 20), 0xF0000000ull);
+        plan.po.output = BASAL_PIPE_OUT_SAM;
+        plan.po.flags = BASAL_PIPE_PAIRS;
+        pipe_thread = std::thread([&] {
+            const double a0 = now();
+            if (basal_pipe_create(core, &plan.po, &pipe)) pipe_err = basal_last_error();
             t_pipe = now() - a0;
         });
     }
@@ -1234,8 +1578,13 @@ int main(int argc, char **argv) {
         uint64_t n_pairs = 0;
         double t_gpu = 0;
         Aligner al{multi ? nullptr : core, multi};
+        if (pe_pipe) {
+            pipe_thread.join();
+            if (!pipe) die("cannot create the pipeline: " + pipe_err);
+        }
         const double tp0 = now();
-        run_pe(cli, al, R, out, pst, n_pairs, t_gpu);
+        if (pe_pipe) run_pe_pipe(cli, pipe, plan.po, out, pst, n_pairs, t_gpu);
+        else run_pe(cli, al, R, out, pst, n_pairs, t_gpu);
         out.close();
         if (cli.verbose >= 1) {
             const double tp1 = now();

@@ -117,7 +117,7 @@ extern "C" int basal_core_set_contig_names(basal_core_t *c, const char *const *n
 static void free_slot(Slot &s) {
     hipFree(s.d.text); hipFree(s.d.raw); hipFree(s.d.desc); hipFree(s.d.aux); hipFree(s.d.stales); hipFree(s.d.npos); hipFree(s.d.bmax1); hipFree(s.d.bmax2);
     hipFree(s.d.defidx); hipFree(s.d.order); hipFree(s.d.results); hipFree(s.d.stream); hipFree(s.d.nl); hipFree(s.d.blk_cnt); hipFree(s.d.out_off); hipFree(s.d.out);
-    hipFree(s.d.cnt); hipFree(s.d.counter); hipFree(s.d.scratch); hipFree(s.d.cub_tmp);
+    hipFree(s.d.cnt); hipFree(s.d.counter); hipFree(s.d.scratch); hipFree(s.d.cub_tmp); hipFree(s.d.pe_pairs); hipFree(s.d.pe_recs); hipFree(s.d.pe_work);
     if (s.h_blob) hipHostFree(s.h_blob);
     if (s.h_raw) hipHostFree(s.h_raw);
     if (s.h_out) hipHostFree(s.h_out);
@@ -159,6 +159,8 @@ extern "C" int basal_pipe_create_multi(basal_core_t *const *cores, int ncores, c
     op.max_bytes = (op.max_bytes + 4095ull) & ~4095ull;
     if (op.max_bytes >= 0xFFFFF000ull) { set_error("pipe_create: max_bytes must stay below 4 GiB (32-bit offsets inside a batch)"); return BASAL_EINVAL; }
     if (op.output > BASAL_PIPE_OUT_RESULTS) { set_error("pipe_create: bad output mode"); return BASAL_EINVAL; }
+    if (op.flags & ~BASAL_PIPE_PAIRS) { set_error("pipe_create: unknown flag"); return BASAL_EINVAL; }
+    if ((op.flags & BASAL_PIPE_PAIRS) && op.output != BASAL_PIPE_OUT_SAM) { set_error("pipe_create: BASAL_PIPE_PAIRS goes with BASAL_PIPE_OUT_SAM"); return BASAL_EINVAL; }
     basal_pipe *p = new basal_pipe();
     p->c = c;
     p->o = op;
@@ -217,9 +219,16 @@ extern "C" int basal_pipe_create_multi(basal_core_t *const *cores, int ncores, c
             TRYD(hipMalloc(&d.out, d.out_cap));
             TRYD(hipMalloc(&d.cub_tmp, cub));
             d.cub_tmp_bytes = cub;
-            if (c->p.report_repeat_hits == 2) {
+            if (c->p.report_repeat_hits == 2 || (op.flags & BASAL_PIPE_PAIRS)) {  // (pairs: every mate's whole hit log, for the pairing kernel)
                 d.stream_cap = (uint64_t)mr * 8 + 4096;
                 TRYD(hipMalloc(&d.stream, d.stream_cap * sizeof(basal_hit)));
+            }
+            if (op.flags & BASAL_PIPE_PAIRS) {
+                d.pe_work_cap = d.stream_cap;
+                d.pe_recs_cap = (uint64_t)mr + 4096;
+                TRYD(hipMalloc(&d.pe_work, d.pe_work_cap * sizeof(basal_hit)));
+                TRYD(hipMalloc(&d.pe_recs, d.pe_recs_cap * sizeof(basal_pe_rec)));
+                TRYD(hipMalloc(&d.pe_pairs, ((size_t)mr / 2 + 1) * sizeof(basal_pe_pair)));
             }
             s.h_out_cap = d.out_cap;
         } else s.h_out_cap = (size_t)mr * sizeof(basal_result);
@@ -303,7 +312,8 @@ static int queue_align(basal_pipe *p, Slot &s) {
     basal_core *c = v.c;
     SlotDev &d = s.d;
     const uint32_t mr = p->o.max_reads;
-    const int smode = p->o.output == BASAL_PIPE_OUT_SAM && c->p.report_repeat_hits == 2 ? BASAL_STREAM_BEST : BASAL_STREAM_NONE;
+    const int smode = (p->o.flags & BASAL_PIPE_PAIRS) ? BASAL_STREAM_ALL
+                      : p->o.output == BASAL_PIPE_OUT_SAM && c->p.report_repeat_hits == 2 ? BASAL_STREAM_BEST : BASAL_STREAM_NONE;
     if (s.mode == MODE_PREPARED) {
         basal_align_extra ex;
         ex.counter = d.counter;
@@ -325,7 +335,22 @@ static int queue_align(basal_pipe *p, Slot &s) {
     return BASAL_OK;
 }
 
-static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, int format, uint32_t first_index, uint32_t readset, uint32_t max_len) {
+// what follows the align launches of a SAM batch: (paired-end: the pairing kernel over the mates' logs, then) the text
+static int queue_format(basal_pipe *p, Slot &s) {
+    PipeDev &v = p->devs[(size_t)s.dev];
+    basal_core *c = v.c;
+    SlotDev &d = s.d;
+    if (!(p->o.flags & BASAL_PIPE_PAIRS)) return prep_enqueue_format(c, p->k, d, v.sh, p->o.max_reads, v.st_comp);
+    const uint32_t npairs = s.n_host / 2;
+    HIP_TRYQ(hipMemsetAsync(&d.cnt->pe[0], 0, sizeof d.cnt->pe, v.st_comp));
+    HIP_TRYQ(hipMemsetAsync(&d.cnt->pe_recs_used, 0, sizeof d.cnt->pe_recs_used, v.st_comp));
+    int rc = basal_pe_enqueue(c, d.desc, d.results, d.stream, d.pe_work, npairs, d.pe_pairs, d.pe_recs, d.pe_recs_cap, &d.cnt->pe_recs_used, d.cnt->pe, v.st_comp);
+    if (rc) return rc;
+    return prep_enqueue_format_pe(c, p->k, d, v.sh, npairs, p->o.max_reads, v.st_comp);
+}
+
+static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, int format, uint32_t first_index, uint32_t readset, uint32_t max_len,
+                         uint32_t pair_split = 0) {
     if (!p) { set_error("pipe_submit: null argument"); return BASAL_EINVAL; }
     int si;
     bool broken;
@@ -352,6 +377,11 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     v.sh.names = c->d_names;
     v.sh.name_off = c->d_name_off;
     if (nbytes > p->o.max_bytes || n > p->o.max_reads) { set_error("pipe_submit: batch larger than the pipe's max_bytes / max_reads"); return fail(BASAL_EINVAL); }
+    if ((p->o.flags & BASAL_PIPE_PAIRS) && (!(mode == MODE_RECORDS || (mode == MODE_TEXT && pair_split)) || (n & 1u) || n == 0)) {
+        set_error("pipe_submit: a paired-end pipe takes submit_records with an even number of records (a0, b0, a1, b1, ...) or submit_text_pairs");
+        return fail(BASAL_EINVAL);
+    }
+    if (pair_split && !(p->o.flags & BASAL_PIPE_PAIRS)) { set_error("pipe_submit_text_pairs: not a paired-end pipe"); return fail(BASAL_EINVAL); }
     if ((mode == MODE_PREPARED) != (p->o.output == BASAL_PIPE_OUT_RESULTS)) { set_error("pipe_submit: prepared reads go with BASAL_PIPE_OUT_RESULTS, text and records with BASAL_PIPE_OUT_SAM"); return fail(BASAL_EINVAL); }
     if (hipSetDevice(c->device) != hipSuccess) { set_error("pipe_submit: hipSetDevice failed"); return fail(BASAL_EDEVICE); }
     SlotDev &d = s.d;
@@ -385,14 +415,15 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
         TRYS(hipMemcpyPeerAsync(v.sh.carry[bno % p->ncarry], c->device, w.sh.carry[bno % p->ncarry], w.c->device, sizeof(CarryState), v.st_comp));
     }
     if (mode != MODE_PREPARED) {
-        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, v.sh, bno, nbytes, format, first_index, p->read_end, readset, mr, v.st_comp));
+        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, v.sh, bno, nbytes, format, first_index, pair_split ? 0xFFFFFFFFu : p->read_end, readset, mr, pair_split, pair_split ? n / 2 : 0, v.st_comp));
         else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, v.st_comp));
         TRYR(prep_enqueue_filter(c, p->k, d, v.sh, bno, mr, true, 0, v.st_comp));
+        if (p->o.flags & BASAL_PIPE_PAIRS) TRYR(prep_enqueue_pair_fix(c, d, n / 2, v.st_comp));
     }
     TRYS(hipEventRecord(s.ev[EV_PREP], v.st_comp));
     TRYR(queue_align(p, s));
     TRYS(hipEventRecord(s.ev[EV_ALIGN], v.st_comp));
-    if (mode != MODE_PREPARED) TRYR(prep_enqueue_format(c, p->k, d, v.sh, mr, v.st_comp));
+    if (mode != MODE_PREPARED) TRYR(queue_format(p, s));
     TRYS(hipEventRecord(s.ev[EV_FORMAT], v.st_comp));
     // copies out: the counters (and the guard ledger) always; the output itself once its size is known
     TRYS(hipStreamWaitEvent(v.st_cnt, s.ev[EV_FORMAT], 0));
@@ -432,6 +463,10 @@ extern "C" int basal_pipe_submit_text(basal_pipe_t *p, uint64_t nbytes, int form
     return submit_common(p, MODE_TEXT, nbytes, 0, format, first_index, readset, 0);
 }
 extern "C" int basal_pipe_submit_records(basal_pipe_t *p, uint64_t nblob, uint32_t n) { return submit_common(p, MODE_RECORDS, nblob, n, 0, 0, 0, 0); }
+extern "C" int basal_pipe_submit_text_pairs(basal_pipe_t *p, uint64_t nbytes, uint64_t split, uint32_t npairs, int format, uint32_t first_index) {
+    if (split == 0 || split >= nbytes || npairs == 0 || npairs > 0x7FFFFFFFu / 2) { set_error("pipe_submit_text_pairs: bad split / pair count"); if (p) basal_pipe_cancel(p); return BASAL_EINVAL; }
+    return submit_common(p, MODE_TEXT, nbytes, 2 * npairs, format, first_index, 0, 0, (uint32_t)split);
+}
 extern "C" int basal_pipe_submit_prepared(basal_pipe_t *p, uint64_t nbases, uint32_t n, uint32_t max_len) {
     if (max_len == 0 || max_len > BASAL_MAXREADLEN) { set_error("pipe_submit_prepared: max_len must be 1..480"); return BASAL_EINVAL; }
     return submit_common(p, MODE_PREPARED, nbases, n, 0, 0, 0, max_len);
@@ -539,13 +574,18 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
                   "parse it on the host and submit it with basal_pipe_submit_records");
         ret = BASAL_EIO;
     }
+    if (!ret && sam && s.h_cnt->pair_err) {
+        set_error("Error: Paired reads name not match (pair " + std::to_string(s.h_cnt->pair_err_at) + " of the batch): the reference exits here (pairs.cpp:501-504)");
+        ret = BASAL_EINVAL;
+    }
     if (!ret && sam) {
-        // rare second passes, with the batch's inputs still on the device: a hit stream (-r 2) or a text buffer that was too small
+        // rare second passes, with the batch's inputs still on the device: a hit stream (-r 2, paired-end) or a text buffer that was too small
         SlotDev &d = s.d;
         for (int pass = 0; pass < 4; pass++) {
             const BatchCounters &cn = *s.h_cnt;
             const bool stream_small = d.stream && cn.stream_used > d.stream_cap, out_small = cn.out_bytes > d.out_cap;
-            if (!stream_small && !out_small && !(cn.irregular & 2u)) break;
+            const bool recs_small = d.pe_recs && cn.pe_recs_used > d.pe_recs_cap;
+            if (!stream_small && !out_small && !recs_small && !(cn.irregular & 2u)) break;
             HIP_TRYQ(hipStreamSynchronize(v.st_comp));
             HIP_TRYQ(hipStreamSynchronize(v.st_cnt));
             if (stream_small || (cn.irregular & 2u)) {
@@ -553,6 +593,18 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
                 d.stream = nullptr;
                 d.stream_cap = cn.stream_used + cn.stream_used / 4 + 4096;
                 HIP_TRYQ(hipMalloc(&d.stream, d.stream_cap * sizeof(basal_hit)));
+                if (d.pe_work) {
+                    hipFree(d.pe_work);
+                    d.pe_work = nullptr;
+                    d.pe_work_cap = d.stream_cap;
+                    HIP_TRYQ(hipMalloc(&d.pe_work, d.pe_work_cap * sizeof(basal_hit)));
+                }
+            }
+            if (recs_small) {
+                hipFree(d.pe_recs);
+                d.pe_recs = nullptr;
+                d.pe_recs_cap = cn.pe_recs_used + cn.pe_recs_used / 4 + 4096;
+                HIP_TRYQ(hipMalloc(&d.pe_recs, d.pe_recs_cap * sizeof(basal_pe_rec)));
             }
             if (out_small) {
                 hipFree(d.out);
@@ -567,7 +619,7 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, v.st_comp));
             HIP_TRYQ(hipStreamSynchronize(v.st_comp));
             if (stream_small || (cn.irregular & 2u)) { int rc = queue_align(p, s); if (rc) return rc; }
-            { int rc = prep_enqueue_format(c, p->k, d, v.sh, p->o.max_reads, v.st_comp); if (rc) return rc; }
+            { int rc = queue_format(p, s); if (rc) return rc; }
             HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, v.st_comp));
             HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, v.st_comp));
             HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), v.st_comp));
@@ -586,6 +638,7 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
         const BatchCounters &cn = *s.h_cnt;
         stats->n_reads = s.mode == MODE_PREPARED ? s.n_host : cn.n_reads;
         stats->n_aligned = cn.n_aligned; stats->n_unique = cn.n_unique; stats->n_multiple = cn.n_multiple; stats->n_filtered = cn.n_filtered;
+        for (int k = 0; k < 9; k++) stats->pe[k] = cn.pe[k];
         if (!ret) {
             hipEventElapsedTime(&stats->ms_h2d, s.ev[EV_START], s.ev[EV_H2D]);
             hipEventElapsedTime(&stats->ms_prep, s.ev[EV_COMP0], s.ev[EV_PREP]);

@@ -53,7 +53,10 @@ struct BatchCounters {
     uint32_t irregular;              // text form: the text is not 4 (2) regular lines per record
     uint32_t n_stale;
     uint32_t cls_n[3];               // reads per length class
-    uint32_t pad;
+    uint32_t pair_err;               // paired-end: a pair whose names differ from the first character on (FixPairReadName exits there) ...
+    uint32_t pair_err_at;            // ... and the first such pair's number in the batch
+    uint32_t pe[9];                  // paired-end: aligned / unique / multiple for pairs, mate 1, mate 2 (pairs.cpp's counters)
+    unsigned long long pe_recs_used; // paired-end: records the pairing kernel wanted to write
 };
 
 // everything one batch slot owns on the device
@@ -76,6 +79,11 @@ struct SlotDev {
     unsigned long long *out_off = nullptr;  // [max_reads + 1] SAM byte offset of every read
     uint8_t *out = nullptr;         // SAM text
     uint64_t out_cap = 0;
+    basal_pe_pair *pe_pairs = nullptr;  // paired-end pipes: [max_reads / 2] per pair, where its records start
+    basal_pe_rec *pe_recs = nullptr;    // the records to print (pairing kernel, basal_pe.hip)
+    uint64_t pe_recs_cap = 0;
+    basal_hit *pe_work = nullptr;       // the pairing kernel's sorted copies of the mates' logs: as many records as the hit stream
+    uint64_t pe_work_cap = 0;
     BatchCounters *cnt = nullptr;
     unsigned int *counter = nullptr;  // [3][32]: align queue head + guard ledger per class launch
     basal_hit *scratch = nullptr;     // per-wave hit logs
@@ -95,13 +103,17 @@ struct PrepShared {  // per pipe, shared by the slots
 int prep_make_const(const basal_params &p, PrepConst &k);
 // queue: text -> raw table (text form only)
 // first_index 0xFFFFFFFF: continue from the carry state's next_index
+// pair_n != 0: the text is mate 1's pair_n records (pair_split bytes) followed by mate 2's pair_n records; the table comes out interleaved
 int prep_enqueue_index_text(basal_core *c, SlotDev &s, const PrepShared &sh, uint32_t batch_no, uint64_t nbytes, int format, uint32_t first_index, uint32_t read_end,
-                            uint32_t readset, uint32_t max_reads, hipStream_t st);
+                            uint32_t readset, uint32_t max_reads, uint32_t pair_split, uint32_t pair_n, hipStream_t st);
 // queue: raw table -> descriptors, QC, stale table, length-class lists, carry state of the next batch
 int prep_enqueue_filter(basal_core *c, const PrepConst &k, SlotDev &s, const PrepShared &sh, uint32_t batch_no, uint32_t max_reads, bool n_on_device,
                         uint32_t n_host, hipStream_t st);
 // queue: results -> SAM text in s.out
 int prep_enqueue_format(basal_core *c, const PrepConst &k, SlotDev &s, const PrepShared &sh, uint32_t max_reads, hipStream_t st);
+// paired-end pipes: FixPairReadName + the every-mode mark (behind the filter), and the pairing kernel's records -> SAM text in s.out
+int prep_enqueue_pair_fix(basal_core *c, SlotDev &s, uint32_t npairs, hipStream_t st);
+int prep_enqueue_format_pe(basal_core *c, const PrepConst &k, SlotDev &s, const PrepShared &sh, uint32_t npairs, uint32_t max_reads, hipStream_t st);
 size_t prep_cub_tmp_bytes(uint32_t max_reads, uint64_t max_bytes);
 
 }  // namespace basal

@@ -100,11 +100,16 @@ __global__ __launch_bounds__(256) void nl_write(const uint8_t *__restrict__ text
 // (`>>` skips white space, reads.cpp:52-74) would disagree is flagged irregular and left to the host parser.
 __global__ __launch_bounds__(256) void build_raw(const uint8_t *__restrict__ text, unsigned long long nbytes, const uint32_t *__restrict__ nl, uint32_t nl_cap,
                                                  int fasta, uint32_t readset, uint32_t first_index, uint32_t read_end, uint32_t max_readlen, uint32_t max_reads,
+                                                 uint32_t pair_split, uint32_t pair_n,
                                                  const CarryState *__restrict__ carry, basal_rawread *__restrict__ raw, BatchCounters *__restrict__ cnt) {
     if (first_index == 0xFFFFFFFFu) first_index = carry->next_index;
     const uint32_t lpr = fasta ? 2u : 4u, n_lines = cnt->n_lines;
     uint32_t nrec = n_lines / lpr;
     bool bad = n_lines % lpr != 0 || n_lines > nl_cap || nrec > max_reads || (nbytes && text[nbytes - 1] != '\n');
+    // paired-end text: mate 1's pair_n records (the first pair_split bytes), then mate 2's pair_n records; record k of either half is mate
+    // k's, and they come out interleaved (a0, b0, a1, b1, ...) with the pair's number as both mates' read number
+    const bool pairs = pair_n != 0;
+    if (pairs && !bad) bad = nrec != 2 * pair_n || nl[lpr * pair_n - 1] + 1 != pair_split;
     if (first_index >= read_end) nrec = 0;
     else if (nrec > read_end - first_index) nrec = read_end - first_index;  // -E: reads beyond read_end are not loaded (reads.cpp:45)
     if (bad) nrec = 0;
@@ -152,11 +157,11 @@ __global__ __launch_bounds__(256) void build_raw(const uint8_t *__restrict__ tex
             rr.seq_off = lb[1];
             rr.seq_len = (uint16_t)sl;
             rr.qual_len = (uint16_t)ql;
-            rr.readset = (uint8_t)readset;
-            rr.index = first_index + k;
+            rr.readset = (uint8_t)(pairs ? (k >= pair_n ? 2u : 1u) : readset);
+            rr.index = first_index + (pairs && k >= pair_n ? k - pair_n : k);
         }
         if (irr) cnt->irregular = 1;
-        raw[k] = rr;
+        raw[pairs ? (k >= pair_n ? 2 * (k - pair_n) + 1 : 2 * k) : k] = rr;
     }
 }
 
@@ -564,6 +569,28 @@ __device__ __forceinline__ void put_seq_qual(S &o, const FmtCtx &f, const basal_
     }
 }
 
+// XR:Z (align.cpp:646-658, pairs.cpp:338-350): 2 lower-case flank bases, len bases, 2 lower-case flank bases of the forward strand
+template <class S>
+__device__ __forceinline__ void put_xr(S &o, const FmtCtx &f, uint32_t contig, uint32_t loc, uint32_t len) {
+    if (contig >= f.ncontig) contig = 0;
+    const uint64_t *s = f.xref_fwd + f.anchor[contig] / 32;
+    put_lit(o, "\tXR:Z:");
+    if constexpr (!S::kWrites) o.skip((loc >= 2) + (loc >= 1) + len + 2);
+    else {
+        // the four letters as one word (a per-lane index into the by-value argument struct would put the struct into scratch memory)
+        const uint32_t nt4 = (uint32_t)(uint8_t)f.k.useful_nt[0] | ((uint32_t)(uint8_t)f.k.useful_nt[1] << 8) | ((uint32_t)(uint8_t)f.k.useful_nt[2] << 16) |
+                             ((uint32_t)(uint8_t)f.k.useful_nt[3] << 24);
+        unsigned long long wcur = ~0ull, word = 0;  // one reference word serves 32 bases
+        auto base_at = [&](uint32_t xx) {
+            if ((xx >> 5) != wcur) { wcur = xx >> 5; word = s[wcur]; }
+            return (nt4 >> (8 * (uint32_t)((word >> (62 - 2 * (xx & 31))) & 3))) & 0xffu;
+        };
+        for (uint32_t q = 2; q > 0; q--)
+            if (loc >= q) o.ch(base_at(loc - q) + 32);
+        for (uint32_t q = 0; q < len + 2; q++) o.ch(base_at(loc + q) + (q >= len ? 32 : 0));
+    }
+}
+
 // n <= 0: unmapped (n < 0: failed QC); else one alignment record
 template <class S>
 __device__ __forceinline__ void put_record(S &o, const FmtCtx &f, const basal_rawread &rr, const ReadAux &a, uint32_t chain, int n, uint32_t level, const basal_hit &h) {
@@ -594,27 +621,7 @@ __device__ __forceinline__ void put_record(S &o, const FmtCtx &f, const basal_ra
     put_lit(o, "\t*\t0\t0\t");
     put_seq_qual(o, f, rr, a, rev);
     put_lit(o, "\tNM:i:"); put_num(o, (long long)(level & 0xffu));
-    if (f.k.out_ref) {  // XR:Z (align.cpp:646-658): 2 lower-case flank bases, len bases, 2 lower-case flank bases of the forward strand
-        uint32_t contig = (h.chr & 0xfffeu) >> 1;  // (the reference masks 16 bits here)
-        if (contig >= f.ncontig) contig = 0;
-        const uint64_t *s = f.xref_fwd + f.anchor[contig] / 32;
-        put_lit(o, "\tXR:Z:");
-        const uint32_t loc = h.loc;
-        if constexpr (!S::kWrites) o.skip((loc >= 2) + (loc >= 1) + len + 2);
-        else {
-            // the four letters as one word (a per-lane index into the by-value argument struct would put the struct into scratch memory)
-            const uint32_t nt4 = (uint32_t)(uint8_t)f.k.useful_nt[0] | ((uint32_t)(uint8_t)f.k.useful_nt[1] << 8) | ((uint32_t)(uint8_t)f.k.useful_nt[2] << 16) |
-                                 ((uint32_t)(uint8_t)f.k.useful_nt[3] << 24);
-            unsigned long long wcur = ~0ull, word = 0;  // one reference word serves 32 bases
-            auto base_at = [&](uint32_t xx) {
-                if ((xx >> 5) != wcur) { wcur = xx >> 5; word = s[wcur]; }
-                return (nt4 >> (8 * (uint32_t)((word >> (62 - 2 * (xx & 31))) & 3))) & 0xffu;
-            };
-            for (uint32_t q = 2; q > 0; q--)
-                if (loc >= q) o.ch(base_at(loc - q) + 32);
-            for (uint32_t q = 0; q < len + 2; q++) o.ch(base_at(loc + q) + (q >= len ? 32 : 0));
-        }
-    }
+    if (f.k.out_ref) put_xr(o, f, (h.chr & 0xfffeu) >> 1, h.loc, len);  // (the reference masks 16 bits here, align.cpp:646-658)
     put_lit(o, "\tZS:Z:"); o.ch((h.chr & 1) ? '-' : '+'); o.ch(chain ? '-' : '+'); o.ch('\n');
 }
 
@@ -688,6 +695,139 @@ __global__ __launch_bounds__(256) void sam_write(FmtCtx f, const uint32_t *__res
     }
 }
 
+
+// ---- paired-end: FixPairReadName, and the text of s_OutHitPair / s_OutHitUnpair (pairs.cpp:307-507) from the pairing kernel's records ----
+// One thread per read pair (records 2 i and 2 i + 1 of the batch). FixPairReadName (pairs.cpp:487-507): names that differ are cut behind the
+// last digit of their common prefix (behind the prefix if it holds none); names that differ from the first character on end the run in the
+// reference (cnt->pair_err). Mates that both passed FilterReads are aligned with every mode (PairAlign::RunAlign drives them, pairs.cpp:132-177).
+__global__ __launch_bounds__(256) void pair_fix(const uint8_t *__restrict__ text, basal_rawread *__restrict__ raw, basal_read *__restrict__ desc,
+                                                const ReadAux *__restrict__ aux, uint32_t npairs, BatchCounters *__restrict__ cnt) {
+    for (uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x; pi < npairs; pi += gridDim.x * blockDim.x) {
+        const basal_rawread a = raw[2 * pi], b = raw[2 * pi + 1];
+        const uint32_t la = a.name_len, lb = b.name_len, i0 = la < lb ? la : lb;
+        uint32_t i = 0;
+        int d = -1;
+        for (; i < i0; i++) {
+            const uint32_t ca = text[a.name_off + i], cb = text[b.name_off + i];
+            if (ca != cb) break;
+            if (ca >= '0' && ca <= '9') d = (int)i;
+        }
+        if (!(la == lb && i == i0)) {
+            if (i > 0) {
+                if (d < 0) d = (int)i - 1;
+                if ((uint32_t)d + 1 < la) raw[2 * pi].name_len = (uint16_t)(d + 1);
+                if ((uint32_t)d + 1 < lb) raw[2 * pi + 1].name_len = (uint16_t)(d + 1);
+            } else if (atomicOr(&cnt->pair_err, 1u) == 0) cnt->pair_err_at = pi;
+        }
+        if (!aux[2 * pi].qc_failed && !aux[2 * pi + 1].qc_failed) {
+            desc[2 * pi].readset |= BASAL_READ_ALLMODES;
+            desc[2 * pi + 1].readset |= BASAL_READ_ALLMODES;
+        }
+    }
+}
+
+struct PeFmt {
+    const basal_pe_pair *pairs;
+    const basal_pe_rec *recs;
+};
+
+template <class S>
+__device__ __forceinline__ void put_contig(S &o, const FmtCtx &f, uint32_t ctg) {
+    if (ctg < f.ncontig) put_bytes(o, (const uint8_t *)f.names + f.name_off[ctg], f.name_off[ctg + 1] - f.name_off[ctg]);
+    else o.ch('*');
+}
+template <class S>
+__device__ __forceinline__ void put_cigar(S &o, const basal_hit &h, uint32_t len) {  // pairs.cpp:329-331
+    if (h.gap_size == 0) { put_num(o, len); o.ch('M'); }
+    else if (h.gap_size > 0) { put_num(o, h.gap_pos); o.ch('M'); put_num(o, h.gap_size); o.ch('D'); put_num(o, (int)len - (int)h.gap_pos); o.ch('M'); }
+    else { put_num(o, h.gap_pos); o.ch('M'); put_num(o, -(int)h.gap_size); o.ch('I'); put_num(o, (int)len - (int)h.gap_pos + (int)h.gap_size); o.ch('M'); }
+}
+
+// every line of one read pair, in the order the records list them
+template <class S>
+__device__ __forceinline__ void put_pair(S &o, const FmtCtx &f, const PeFmt &pf, uint32_t pi) {
+    const basal_pe_pair pr = pf.pairs[pi];
+    for (uint32_t k = 0; k < pr.n; k++) {
+        const basal_pe_rec e = pf.recs[pr.first + k];
+        if (e.kind == BASAL_PE_PAIR) {  // s_OutHitPair, pairs.cpp:307-411: mate 1's line, then mate 2's
+            const uint32_t chain = e.chain_a;
+            for (uint32_t side = 0; side < 2; side++) {
+                const uint32_t r = 2 * pi + side;
+                const basal_rawread rr = f.raw[r];
+                const ReadAux ax = f.aux[r];
+                const basal_hit h = side ? e.hb : e.ha, mh = side ? e.ha : e.hb;
+                const bool rev = side ? (((chain == 0) ? 1u : 0u) ^ (h.chr & 1u)) != 0 : ((chain ^ (h.chr & 1u)) != 0);
+                int flag = 0x3 | (e.ma > 1 ? 0x100 : 0) | (rev ? 0x10 : 0x20) | (int)(0x40 * rr.readset);
+                put_bytes(o, f.text + rr.name_off, rr.name_len); o.ch('\t'); put_num(o, flag); o.ch('\t'); put_contig(o, f, h.chr >> 1); o.ch('\t');
+                put_num(o, (long long)h.loc + 1); put_lit(o, "\t255\t"); put_cigar(o, h, ax.seq_len); put_lit(o, "\t=\t"); put_num(o, (long long)mh.loc + 1); o.ch('\t');
+                put_num(o, rev ? -(long long)e.insert : (long long)e.insert); o.ch('\t');
+                put_seq_qual(o, f, rr, ax, rev);
+                put_lit(o, "\tNM:i:"); put_num(o, (long long)((side ? (uint32_t)e.mb : e.na) & 0xffu));
+                if (f.k.out_ref) put_xr(o, f, h.chr >> 1, h.loc, ax.seq_len);
+                put_lit(o, "\tZS:Z:"); o.ch((h.chr & 1) ? '-' : '+'); o.ch((side ? chain == 0 : chain != 0) ? '-' : '+'); o.ch('\n');
+            }
+        } else {  // s_OutHitUnpair, pairs.cpp:418-485: one line of mate e.side
+            const uint32_t r = 2 * pi + (e.side ? 1u : 0u);
+            const basal_rawread rr = f.raw[r];
+            const ReadAux ax = f.aux[r];
+            const basal_hit ha = e.ha, hb = e.hb;
+            const int ma = e.ma, mb = e.mb;
+            int flag = 1 | (int)(0x40 * rr.readset);
+            const bool rev = ((uint32_t)e.chain_a ^ (ha.chr & 1u)) != 0;
+            if (ma <= 0) {
+                flag |= ma < 0 ? 0x204 : 0x004;
+                if (mb <= 0) {
+                    flag |= 0x008;
+                    put_bytes(o, f.text + rr.name_off, rr.name_len); o.ch('\t'); put_num(o, flag); put_lit(o, "\t*\t0\t0\t*\t*\t0\t0\t");
+                } else {
+                    if ((uint32_t)e.chain_b ^ (hb.chr & 1u)) flag |= 0x020;
+                    put_bytes(o, f.text + rr.name_off, rr.name_len); o.ch('\t'); put_num(o, flag); put_lit(o, "\t*\t0\t0\t*\t"); put_contig(o, f, hb.chr >> 1); o.ch('\t');
+                    put_num(o, (long long)hb.loc + 1); put_lit(o, "\t0\t");
+                }
+                put_seq_qual(o, f, rr, ax, false);
+                o.ch('\n');
+                continue;
+            }
+            if (ma > 1) flag |= 0x100;
+            if (rev) flag |= 0x010;
+            if (mb <= 0) flag |= 0x008;
+            else if ((uint32_t)e.chain_b ^ (hb.chr & 1u)) flag |= 0x020;
+            put_bytes(o, f.text + rr.name_off, rr.name_len); o.ch('\t'); put_num(o, flag); o.ch('\t'); put_contig(o, f, ha.chr >> 1); o.ch('\t');
+            put_num(o, (long long)ha.loc + 1); put_lit(o, "\t255\t"); put_cigar(o, ha, ax.seq_len);
+            if (mb <= 0) put_lit(o, "\t*\t0\t0\t");
+            else { o.ch('\t'); put_contig(o, f, hb.chr >> 1); o.ch('\t'); put_num(o, (long long)hb.loc + 1); put_lit(o, "\t0\t"); }
+            put_seq_qual(o, f, rr, ax, rev);
+            put_lit(o, "\tNM:i:"); put_num(o, (long long)(int)e.na);
+            if (f.k.out_ref) put_xr(o, f, ha.chr >> 1, ha.loc, ax.seq_len);
+            put_lit(o, "\tZS:Z:"); o.ch((ha.chr & 1) ? '-' : '+'); o.ch(e.chain_a ? '-' : '+'); o.ch('\n');
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pe_lengths(FmtCtx f, PeFmt pf, uint32_t npairs, uint32_t max_reads, unsigned long long *__restrict__ out_off) {
+    for (uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x; pi <= max_reads; pi += gridDim.x * blockDim.x) {
+        unsigned long long len = 0;
+        if (pi < npairs && pf.pairs[pi].status == 0) {
+            CountSink o;
+            put_pair(o, f, pf, pi);
+            len = o.n;
+        }
+        out_off[pi] = len;
+    }
+}
+
+__global__ __launch_bounds__(256) void pe_write(FmtCtx f, PeFmt pf, uint32_t npairs, const unsigned long long *__restrict__ out_off, uint8_t *__restrict__ out,
+                                                unsigned long long out_cap, BatchCounters *__restrict__ cnt) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->out_bytes = out_off[npairs];
+    if (out_off[npairs] > out_cap) return;  // the host grows the buffer and queues this kernel again
+    for (uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x; pi < npairs; pi += gridDim.x * blockDim.x) {
+        if (out_off[pi + 1] == out_off[pi]) continue;
+        WriteSink o(out + out_off[pi]);
+        put_pair(o, f, pf, pi);
+        o.flush();
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host: queueing
@@ -727,7 +867,7 @@ size_t prep_cub_tmp_bytes(uint32_t max_reads, uint64_t max_bytes) {
 }
 
 int prep_enqueue_index_text(basal_core *c, SlotDev &s, const PrepShared &sh, uint32_t batch_no, uint64_t nbytes, int format, uint32_t first_index, uint32_t read_end,
-                            uint32_t readset, uint32_t max_reads, hipStream_t st) {
+                            uint32_t readset, uint32_t max_reads, uint32_t pair_split, uint32_t pair_n, hipStream_t st) {
     const uint32_t nblk = (uint32_t)((nbytes + kTextBlock - 1) / kTextBlock);
     if (nblk == 0) return BASAL_OK;  // an empty text: counters stay zero
     hipLaunchKernelGGL(nl_count, dim3(nblk), dim3(256), 0, st, s.text, (unsigned long long)nbytes, s.blk_cnt);
@@ -736,7 +876,7 @@ int prep_enqueue_index_text(basal_core *c, SlotDev &s, const PrepShared &sh, uin
     const uint32_t nl_cap = 4 * max_reads;
     hipLaunchKernelGGL(nl_write, dim3(nblk), dim3(256), 0, st, s.text, (unsigned long long)nbytes, s.blk_cnt, nblk, s.nl, nl_cap, s.cnt);
     hipLaunchKernelGGL(build_raw, dim3(grid_for(max_reads, 256, c)), dim3(256), 0, st, s.text, (unsigned long long)nbytes, s.nl, nl_cap, format == BASAL_FMT_FASTA ? 1 : 0,
-                       readset, first_index, read_end, c->p.max_readlen, max_reads, sh.carry[batch_no % sh.ncarry], s.raw, s.cnt);
+                       readset, first_index, read_end, c->p.max_readlen, max_reads, pair_split, pair_n, sh.carry[batch_no % sh.ncarry], s.raw, s.cnt);
     HIP_TRYP(hipGetLastError());
     return BASAL_OK;
 }
@@ -787,6 +927,29 @@ int prep_enqueue_format(basal_core *c, const PrepConst &k, SlotDev &s, const Pre
     size_t tb = s.cub_tmp_bytes;
     HIP_TRYP(hipcub::DeviceScan::ExclusiveSum(s.cub_tmp, tb, s.out_off, s.out_off, (size_t)max_reads + 1, st));
     hipLaunchKernelGGL(sam_write, dim3(grid_for(max_reads, 256, c)), dim3(256), 0, st, f, n_ptr, 0u, s.out_off, s.out, (unsigned long long)s.out_cap, s.cnt);
+    HIP_TRYP(hipGetLastError());
+    return BASAL_OK;
+}
+
+
+// paired-end: FixPairReadName + the every-mode mark, right behind filter_reads (n = 2 * npairs records, known on the host)
+int prep_enqueue_pair_fix(basal_core *c, SlotDev &s, uint32_t npairs, hipStream_t st) {
+    if (!npairs) return BASAL_OK;
+    hipLaunchKernelGGL(pair_fix, dim3(grid_for(npairs, 256, c)), dim3(256), 0, st, s.text, s.raw, s.desc, s.aux, npairs, s.cnt);
+    HIP_TRYP(hipGetLastError());
+    return BASAL_OK;
+}
+
+// paired-end: the records of the pairing kernel (s.pe_pairs / s.pe_recs) -> SAM text in s.out
+int prep_enqueue_format_pe(basal_core *c, const PrepConst &k, SlotDev &s, const PrepShared &sh, uint32_t npairs, uint32_t max_reads, hipStream_t st) {
+    FmtCtx f;
+    f.k = k; f.text = s.text; f.raw = s.raw; f.aux = s.aux; f.res = s.results; f.stream = s.stream; f.names = sh.names; f.name_off = sh.name_off;
+    f.xref_fwd = c->d_xref[0]; f.anchor = c->d_anchor; f.ncontig = c->ncontig;
+    PeFmt pf{s.pe_pairs, s.pe_recs};
+    hipLaunchKernelGGL(pe_lengths, dim3(grid_for((uint64_t)max_reads + 1, 256, c)), dim3(256), 0, st, f, pf, npairs, max_reads, s.out_off);
+    size_t tb = s.cub_tmp_bytes;
+    HIP_TRYP(hipcub::DeviceScan::ExclusiveSum(s.cub_tmp, tb, s.out_off, s.out_off, (size_t)max_reads + 1, st));
+    hipLaunchKernelGGL(pe_write, dim3(grid_for(npairs ? npairs : 1, 256, c)), dim3(256), 0, st, f, pf, npairs, s.out_off, s.out, (unsigned long long)s.out_cap, s.cnt);
     HIP_TRYP(hipGetLastError());
     return BASAL_OK;
 }

@@ -214,8 +214,11 @@ typedef struct basal_pipe_opts {
     uint32_t max_reads;      /* reads per batch (0 = 4 Mi) */
     uint64_t max_bytes;      /* input bytes per batch, < 4 GiB (0 = 512 MiB) */
     uint32_t output;         /* BASAL_PIPE_OUT_* */
-    uint32_t reserved;
+    uint32_t flags;          /* BASAL_PIPE_PAIRS */
 } basal_pipe_opts;
+#define BASAL_PIPE_PAIRS 1u      /* paired-end (PairAlign::Do_Batch, pairs.cpp:179-202): submit_records takes mate pairs interleaved (a0, b0, a1, b1, ...;
+                                  * readset 1 / 2), FilterReads x 2, FixPairReadName, both mates' alignment, the pairing rounds and the text of
+                                  * s_OutHitPair / s_OutHitUnpair all run on the device; output is the pairs' SAM text, stats->pe the nine counters */
 #define BASAL_PIPE_OUT_SAM 0     /* SAM text (s_OutHit), reads in input order */
 #define BASAL_PIPE_OUT_RESULTS 1 /* basal_result[n] (+ nothing else): what a multi-GPU gather moves */
 #define BASAL_FMT_FASTQ 0
@@ -224,6 +227,8 @@ typedef struct basal_pipe_opts {
 typedef struct basal_batch_stats { /* main.cpp:606-612 */
     uint64_t n_reads, n_aligned, n_unique, n_multiple, n_filtered;
     float ms_h2d, ms_prep, ms_align, ms_format, ms_d2h; /* HIP-event times of this batch's stages on its stream */
+    uint32_t pe[9];  /* BASAL_PIPE_PAIRS: aligned / unique / multiple for pairs, mate 1, mate 2 (main.cpp:114-117) */
+    uint32_t pad;
 } basal_batch_stats;
 
 int basal_pipe_create(basal_core_t *c, const basal_pipe_opts *o, basal_pipe_t **out);
@@ -244,6 +249,10 @@ int basal_pipe_acquire(basal_pipe_t *p, uint8_t **blob, basal_rawread **raw);
  * for that batch -- re-submit it through submit_records after parsing it on the host. */
 int basal_pipe_submit_text(basal_pipe_t *p, uint64_t nbytes, int format, uint32_t first_index, uint32_t readset);
 int basal_pipe_submit_records(basal_pipe_t *p, uint64_t nblob, uint32_t n);
+/* BASAL_PIPE_PAIRS pipes, text form: the blob holds mate 1's `npairs` records (`split` bytes of FASTQ / FASTA-reads text) followed by mate
+ * 2's `npairs` records (the caller only has to count lines to cut the two files alike); pair i gets read number first_index + i. A text the
+ * device finds irregular -- or whose halves do not hold npairs records each -- is refused like submit_text's (collect: BASAL_EIO). */
+int basal_pipe_submit_text_pairs(basal_pipe_t *p, uint64_t nbytes, uint64_t split, uint32_t npairs, int format, uint32_t first_index);
 /* Already QC-filtered reads (the basal_core_align_batch input) in the acquired slot's blob: bases at blob[0..nbases), the n
  * descriptors written to (basal_read *)raw by the caller. Output must be BASAL_PIPE_OUT_RESULTS. */
 int basal_pipe_submit_prepared(basal_pipe_t *p, uint64_t nbases, uint32_t n, uint32_t max_len);

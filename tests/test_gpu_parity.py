@@ -212,6 +212,35 @@ def test_cli_pe_small_batches(name, tmp_path):
     assert "".join(l for l in open(out) if not l.startswith("@PG")) == H.golden_sam(name)
 
 
+@pytest.mark.parametrize("form", ["text", "text_small", "blank_line", "host_pairing"])
+@pytest.mark.parametrize("name", H.PE)
+def test_cli_pe_plain_text_files(name, form, tmp_path):
+    """Uncompressed mate files go to the GPU as text (mate 1's records of a batch, then mate 2's: basal_pipe_submit_text_pairs); the .gz form
+    of the fixtures above is parsed by the host's two reader threads.  text_small: batches of 32 pairs (hundreds of hand-overs of the carry
+    state, batches cut by counting newlines); blank_line: a blank line in the middle of mate 2's file -- the device refuses that batch and
+    the run continues in the parsed form from its first bytes; host_pairing: round 2's path (pairing and text on the host) as a cross-check."""
+    import gzip
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    t1, t2 = gzip.open(fq, "rb").read(), gzip.open(fq2, "rb").read()
+    if form == "blank_line":
+        lines = t2.split(b"\n")
+        at = (len(lines) // 8) * 4
+        t2 = b"\n".join(lines[:at] + [b""] + lines[at:])
+    f1.write_bytes(t1)
+    f2.write_bytes(t2)
+    out = tmp_path / "o.sam"
+    env = dict(os.environ, **({"BASAL_PE_HOST_PAIRING": "1"} if form == "host_pairing" else {}))
+    r = subprocess.run([BASAL_BIN, "-a", str(f1), "-b", str(f2), "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "3", "-o", str(out)] +
+                       (["-Z", "64"] if form != "text" else []), capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    if form == "blank_line":
+        assert "parsing them on the host" in r.stderr
+    elif form in ("text", "text_small"):
+        assert "parsing them on the host" not in r.stderr
+    assert "".join(l for l in open(out) if not l.startswith("@PG")) == H.golden_sam(name)
+
+
 def test_abi_edge_cases():
     """Empty batch, skipped descriptors, a hit stream that is too small (BASAL_EOVERFLOW, then a retry with the
     capacity the call reported), a read longer than the batch's longest kernel bound."""
