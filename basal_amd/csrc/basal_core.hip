@@ -1795,7 +1795,8 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
 #define BASAL_W4H 6  // HEAVY: the survivor list makes the LDS 24 KB per block (six blocks per CU), and the long-list loop wants its registers
 #endif
 constexpr int waves_per_simd(int nwt, bool gap, bool heavy = false) {
-    return nwt == 4 ? (gap ? BASAL_W4G : heavy ? BASAL_W4H : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : BASAL_W8NG) : (gap ? BASAL_W16G : BASAL_W16NG);
+    // (HEAVY with longer reads: the survivor list and the Bloom filter leave the LDS room for 4 / 3 blocks per CU)
+    return nwt == 4 ? (gap ? BASAL_W4G : heavy ? BASAL_W4H : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : heavy ? 4 : BASAL_W8NG) : (gap ? BASAL_W16G : heavy ? 3 : BASAL_W16NG);
 }
 
 template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
