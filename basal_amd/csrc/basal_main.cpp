@@ -16,6 +16,7 @@
 #endif
 
 #include <atomic>
+#include <csignal>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -33,9 +34,24 @@ namespace {
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// -o to a regular file is written through a shared mapping of a file grown ahead of the data (Output): whatever ends the run cuts the padding off
+static int g_out_fd = -1;
+static std::atomic<unsigned long long> g_out_off{0};
+static void trim_output() {
+    if (g_out_fd >= 0 && ftruncate(g_out_fd, (off_t)g_out_off.load()) != 0) {}
+}
+
 void die(const std::string &m, int code = 1) {
     fprintf(stderr, "%s\n", m.c_str());
+    trim_output();
     exit(code);
+}
+// a store into the output mapping that the file system cannot back (disk full, quota): a write error, not a crash
+static void on_sigbus(int) {
+    static const char msg[] = "write failed on the output file (no space left on the device?)\n";
+    if (::write(2, msg, sizeof msg - 1) < 0) {}
+    trim_output();
+    _exit(1);
 }
 
 // ---- streaming input: a sliding window over the (gzip-transparent) byte stream; iostream-token semantics of ReadClass::LoadBatchReads ----
@@ -372,8 +388,10 @@ struct Output {
             return;
         }
         if (off + n > size) {
+            // (grown with ftruncate: posix_fallocate makes tmpfs and the page cache touch every page twice, 21 -> 17 Mreads/s into /dev/shm. A full
+            // disk or a quota then shows at the first store into the hole, as SIGBUS: on_sigbus reports it as the write error it is)
             size = off + n + (n < (64u << 20) ? (64u << 20) : 4 * (uint64_t)n);
-            if (ftruncate(fd, (off_t)size) != 0) die("cannot grow the output file");
+            if (ftruncate(fd, (off_t)size) != 0) die(std::string("cannot grow the output file: ") + strerror(errno));
         }
         const uint64_t page = 4096, m0 = off & ~(page - 1);
         const size_t mlen = (size_t)(off + n - m0);
@@ -386,6 +404,7 @@ struct Output {
                 done += (size_t)w;
             }
             off += n;
+            g_out_off.store(off);
             return;
         }
         char *dst = m + (off - m0);
@@ -402,10 +421,11 @@ struct Output {
         }
         munmap(m, mlen);
         off += n;
+        g_out_off.store(off);
     }
     void close() {
         if (piped) pclose(fo);
-        else if (regular) { if (ftruncate(fd, (off_t)off) != 0) die("cannot set the size of the output file"); ::close(fd); }
+        else if (regular) { g_out_fd = -1; if (ftruncate(fd, (off_t)off) != 0) die("cannot set the size of the output file"); ::close(fd); }
         else if (fo != stdout) fclose(fo);
         else fflush(stdout);
     }
@@ -1249,6 +1269,8 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
         ra_.clear(); rb_.clear();
         const bool ga = qa.pop(ra_), gb = ga && qb.pop(rb_);
         tm[0] += now() - q0;
+        if (ga && gb && !ra_.empty() && ra_.size() != rb_.size() && cli.verbose >= 1)
+            fprintf(stderr, "[BASAL-MI355X] warning: the mate files do not hold the same number of reads; stopping at read pair %u\n", ra_[0].index);
         if (!ga || !gb || ra_.empty() || ra_.size() != rb_.size()) break;
         const size_t np = ra_.size();
         q0 = now();
@@ -1385,7 +1407,8 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
         new std::deque<std::vector<Rec>>(std::move(qa.q));
         new std::deque<std::vector<Rec>>(std::move(qb.q));
     }
-    n_pairs = ra.index - cli.read_start + 1;
+    // (n_pairs: the pairs of the batches that were aligned and written -- not the mate-1 reader's position, which runs ahead and counts a
+    // last batch that mate 2's file no longer matched)
     ra.close();
     rb.close();
 }
@@ -1562,6 +1585,7 @@ int main(int argc, char **argv) {
             if (out.fd < 0) die("failed to open output file (check -o option): " + cli.out_file);
             struct stat sb;
             out.regular = fstat(out.fd, &sb) == 0 && S_ISREG(sb.st_mode);
+            if (out.regular) { g_out_fd = out.fd; signal(SIGBUS, on_sigbus); }
             if (!out.regular) { out.fo = fdopen(out.fd, "w"); if (!out.fo) die("failed to open output file (check -o option): " + cli.out_file); }
         }
     }
