@@ -115,10 +115,11 @@ def test_heavy_kernels_on_every_fixture(heavy_m):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BASAL_HEAVY="1", BASAL_HEAVY_M=heavy_m)
-    # (heavy_m 3 also runs the command line on every fixture: the batch pipeline launches the same kernels through its own slots)
+    # (heavy_m 3 also runs the command line on every fixture, single- and paired-end: the batch pipeline launches the same kernels through its own
+    # slots, and the mates of a pair run every mode through them)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "test_hit_logs_match_oracle or test_sam_matches_golden_through_abi or test_small_batches_carry_state" +
-                        (" or test_cli_sam_matches_golden" if heavy_m == "3" else "")],
+                        (" or test_cli_sam_matches_golden or test_cli_pe_sam_matches_golden" if heavy_m == "3" else "")],
                        capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     m = re.search(r"(\d+) passed", r.stdout)
