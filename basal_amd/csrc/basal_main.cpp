@@ -1495,10 +1495,11 @@ int main(int argc, char **argv) {
     std::vector<basal_core_t *> cores;  // single-end on several GPUs: one core per GPU behind ONE batch pipeline (basal_pipe_create_multi)
     if (cli.devices.empty()) cli.devices.push_back(cli.device);
     const bool several = cli.devices.size() > 1 || getenv("BASAL_FORCE_MULTI") != nullptr;  // (the variable: the several-GPU paths on a one-GPU box, for tests)
-    // Single-end: whole batches fan out over the GPUs, each through the device-side pipeline (text in, SAM out); a GPU may be listed twice
-    // (two cores on one GPU: how the tests drive two ranks on a one-GPU box). Paired-end: the batch is sharded over the GPUs and the records
-    // come back through one RCCL gather (basal_multi_*); BASAL_MULTI_HOST=1 sends single-end reads that way too (host-side QC and SAM text).
-    const bool se_pipes = !P.pairend && !getenv("BASAL_MULTI_HOST");
+    // Whole batches fan out over the GPUs, each through the device-side pipeline (text or records in, SAM out; single- and paired-end); a GPU
+    // may be listed twice (two cores on one GPU: how the tests drive two ranks on a one-GPU box). BASAL_MULTI_HOST=1: the batch is sharded over
+    // the GPUs instead and the records come back through one RCCL gather (basal_multi_*: host-side QC and SAM text).
+    // (paired-end with BASAL_PE_HOST_PAIRING / BASAL_PE_NO_PIPE keeps round 2's host-side path, which shards over several GPUs through basal_multi_*)
+    const bool se_pipes = !getenv("BASAL_MULTI_HOST") && !(P.pairend && (getenv("BASAL_PE_HOST_PAIRING") || getenv("BASAL_PE_NO_PIPE")));
     if (several && !se_pipes) {
         if (basal_multi_create(&P, cli.devices.data(), (int)cli.devices.size(), &multi)) die(std::string("cannot set up the GPUs: ") + basal_last_error());
         core = basal_multi_core(multi, 0);
@@ -1507,7 +1508,7 @@ int main(int argc, char **argv) {
             basal_core_t *c1 = nullptr;
             if (basal_core_create(&P, dv, &c1)) die(std::string("cannot create the GPU core: ") + basal_last_error());
             cores.push_back(c1);
-            if (P.pairend || !several) break;
+            if (!several) break;
         }
         core = cores[0];
     }
@@ -1537,7 +1538,7 @@ int main(int argc, char **argv) {
         plan.po.flags = BASAL_PIPE_PAIRS;
         pipe_thread = std::thread([&] {
             const double a0 = now();
-            if (basal_pipe_create(core, &plan.po, &pipe)) pipe_err = basal_last_error();
+            if (basal_pipe_create_multi(cores.data(), (int)cores.size(), &plan.po, &pipe)) pipe_err = basal_last_error();
             t_pipe = now() - a0;
         });
     }

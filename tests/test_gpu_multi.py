@@ -48,8 +48,8 @@ def test_multi_align_batch_equals_core_align_batch(name, mode):
 
 @pytest.mark.parametrize("name", ["ct_basic", "varlen_trim", "rep_r2_w10", "tdel_pipeline", "pe_ct_100_u", "pe_rep_r2"])
 def test_cli_sharded_path_matches_golden(name, tmp_path):
-    """Paired-end `basal -G 0,1,...` and, with BASAL_MULTI_HOST, single-end too take the sharded path (host QC and SAM text,
-    basal_multi_align_batch); BASAL_FORCE_MULTI runs it on one GPU."""
+    """With BASAL_MULTI_HOST `basal -G 0,1,...` takes the sharded path (host QC and SAM text, basal_multi_align_batch, one RCCL gather per
+    batch); BASAL_FORCE_MULTI runs it on one GPU."""
     fa, fq, fq2, _ = H.fixture_paths(name)
     pe = H.MANIFEST[name]["pe"]
     out = tmp_path / "o.sam"
@@ -83,6 +83,22 @@ def test_cli_two_ranks_one_pipeline_matches_golden(name, gpus, pipe_bytes, tmp_p
     assert r.returncode == 0, r.stderr
     got = "".join(l for l in open(out) if not l.startswith("@PG"))
     assert got == H.golden_sam(name)
+
+
+@pytest.mark.parametrize("name", [n for n in H.MANIFEST if H.MANIFEST[n]["pe"]])
+def test_cli_two_ranks_paired_end_matches_golden(name, tmp_path):
+    """`basal -b ... -G 0,0`: the paired-end pipeline over two cores, 32 pairs per batch (the carry state of both mates' slots crosses from rank
+    to rank with every batch), plain-text mate files."""
+    import gzip
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(gzip.open(fq, "rb").read())
+    f2.write_bytes(gzip.open(fq2, "rb").read())
+    out = tmp_path / "o.sam"
+    r = subprocess.run([BASAL_BIN, "-a", str(f1), "-b", str(f2), "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "4", "-G", "0,0", "-Z", "64", "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "".join(l for l in open(out) if not l.startswith("@PG")) == H.golden_sam(name)
 
 
 def test_pipe_two_ranks_equals_one_rank():
