@@ -1246,13 +1246,15 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
             struct S1 { uint64_t a, b; };
             struct S2 { uint32_t loc; uint64_t f; };
             auto jj_of = [&](uint32_t p) { uint32_t jj = l_jj0 + p; return jj >= l_m ? jj - l_m : jj; };
+            // (the stream is read once: non-temporal loads keep it from pushing the index tables and reference lines out of the caches, +1.5 %;
+            // the same hint on the survivors' reference words, five loads into one line, cost 20 %)
             auto issue1 = [&](uint32_t p0) {
                 S1 c = {0, 0};
                 const uint32_t p = p0 + (uint32_t)lane;
                 if (p < l_m) {
                     const uint32_t jj = jj_of(p);
-                    if (has_a) c.a = Fa[jj];
-                    if (has_b) c.b = Fb[jj];
+                    if (has_a) c.a = __builtin_nontemporal_load(&Fa[jj]);
+                    if (has_b) c.b = __builtin_nontemporal_load(&Fb[jj]);
                 }
                 return c;
             };
@@ -1264,8 +1266,8 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 S2 c = {0, 0};
                 if (want) {
                     const uint32_t jj = jj_of(p0 + (uint32_t)lane);
-                    c.loc = Lc[jj];
-                    if (has_f) c.f = Ff[jj];
+                    c.loc = __builtin_nontemporal_load(&Lc[jj]);
+                    if (has_f) c.f = __builtin_nontemporal_load(&Ff[jj]);
                 }
                 return c;
             };
