@@ -971,9 +971,9 @@ __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L
         uint32_t jj = e_jj0 + (t - e_pre);
         if (jj >= e_m) jj -= e_m;
         const uint32_t x = e_off + jj;  // inside locs[] (the mode's set-up checked off + m per seed); kmer_off is 32-bit, so list positions are too
-        c.loc_raw = cx.locs[x];
-        if (BOTH) { c.f = cx.flank_a[x]; c.fb = cx.flank_a[flank_b_off + x]; c.f2 = cx.flank_a[(2ULL + (e_hcs >> 17)) * flank_b_off + x]; }
-        else c.f = cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)];
+        // (the stream is read once: non-temporal loads in the non-GAP kernels, +1 % there; the GAP kernels lost 1.5 % with them)
+        if (BOTH) { c.loc_raw = cx.locs[x]; c.f = cx.flank_a[x]; c.fb = cx.flank_a[flank_b_off + x]; c.f2 = cx.flank_a[(2ULL + (e_hcs >> 17)) * flank_b_off + x]; }
+        else { c.loc_raw = __builtin_nontemporal_load(&cx.locs[x]); c.f = __builtin_nontemporal_load(&cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)]); }
         c.ei = ei;
         c.jj = jj;
     }
