@@ -325,3 +325,18 @@ def test_transcriptome_100k_contigs_matches_oracle_on_sample():
     assert both.mean() > 0.9
     assert ((res["best"]["chr"][:npairs] >> 1) == (res["best"]["chr"][npairs:] >> 1))[both].all()
     assert run(core, hb, descs, split=41_111).tobytes() == res.tobytes()
+
+
+def test_bench_on_a_fasta_file(tmp_path):
+    """bench.py --fasta (or BASAL_HG38_FASTA): the genome comes from a file through the product's loader, the reads are sampled from it, the
+    sample is checked against the oracle as for the synthetic genomes -- the path a real hg38 takes the day one is on the box."""
+    import json
+    import subprocess
+    fa = H.fixture_paths("ct_basic")[0]
+    env = dict(os.environ, BASAL_BENCH_NO_H2H="1", BASAL_BENCH_NO_UNIFORM="1")
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--fasta", fa, "--batch", "100000", "--steps", "1", "--cpu-sample", "20000", "--ref-sample", "0"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and "identical to the oracle" in d["cpu_baseline"]["sample"]
+    assert "ct_basic" in d["config"]["workload"]
