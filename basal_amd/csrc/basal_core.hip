@@ -58,6 +58,7 @@ struct DevCtx {
     uint32_t ncontig;
     const uint32_t *kmer_off, *kmer_nfwd, *locs;
     const uint64_t *flank_a, *flank_b;  // 32 reference bases after / before each index entry's seed
+    const uint32_t *seedw;              // HEAVY kernels: each index entry's own 16 bases
     uint32_t max_kmer_num;
     uint32_t heavy_m;     // HEAVY kernels: a list of at least this many entries is streamed on its own through the three-window test (heavy_mode)
     uint32_t win2_min_T;  // a mode's stream of at least this many candidates tests filter survivors against the second window (process_read); ~0u = never
@@ -230,7 +231,7 @@ template <bool HEAVY>
 struct HeavyLds {};
 template <>
 struct HeavyLds<true> {
-    SurvEnt surv[128];    // meta = reference strand | read chain << 1
+    SurvEnt surv[128];    // meta = reference strand | read chain << 1 | counted exactly already << 2 | that count << 3
     uint32_t bloom[128];  // a 4096-bit Bloom filter over the keys of ALL stored hits of the read (bulk_add)
     uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
@@ -1160,8 +1161,11 @@ __device__ bool heavy_flush(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
         const SurvEnt sv = L.surv[lane];
         loc = sv.loc; strand = sv.meta & 1u; chain = (sv.meta >> 1) & 1u;
         if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
-        const uint32_t off2 = (loc & 31) * 2, nw = (rc.len + (loc & 31) + 31) / 32;
-        mm = count_mismatch<NWT, NEWRULE>((strand ? cx.xref[1] : cx.xref[0]) + (loc >> 5), L.q[chain], off2, nw, st.thr, rc.n_count);
+        if (sv.meta & 4u) mm = sv.meta >> 3;  // a `full` long list's candidate: counted exactly from the stream (heavy_mode)
+        else {
+            const uint32_t off2 = (loc & 31) * 2, nw = (rc.len + (loc & 31) + 31) / 32;
+            mm = count_mismatch<NWT, NEWRULE>((strand ? cx.xref[1] : cx.xref[0]) + (loc >> 5), L.q[chain], off2, nw, st.thr, rc.n_count);
+        }
     }
     PH(PH_SCORE);
     const bool stop = bulk_add(cx, L, st, log, rc, active, loc, strand, chain, mm, mode, r, lane);
@@ -1225,26 +1229,58 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
         if (eh < 0) break;
         {   // one long list: entry eh
             const uint32_t l_off = rfl(L.ent[eh].off), l_m = rfl(L.ent[eh].m), l_nfwd = rfl(L.ent[eh].nfwd), l_jj0 = rfl(L.ent[eh].jj0), l_hcs = rfl(L.ent[eh].hcs);
-            const uint32_t h = l_hcs & 0xffffu, chain = (l_hcs >> 16) & 1u, side = l_hcs >> 17;
-            // the read's windows opposite the 32 bases after the seed, the 32 before it, and the next 32 on the side with more read bases
-            uint64_t ra, ma, ca, rb, mb, cb, rf, mf, cf;
-            plane_window3<NWT, NEWRULE>(L.q[chain], (int)(h + cx.K), ra, ma, ca);
-            plane_window3<NWT, NEWRULE>(L.q[chain], (int)h - 32, rb, mb, cb);
-            plane_window3<NWT, NEWRULE>(L.q[chain], side ? (int)h - 64 : (int)(h + cx.K + 32), rf, mf, cf);
-            ra = rdlane64(ra, 0); ma = rdlane64(ma, 0); rb = rdlane64(rb, 0); mb = rdlane64(mb, 0); rf = rdlane64(rf, 0); mf = rdlane64(mf, 0);
-            if (NEWRULE) { ca = rdlane64(ca, 0); cb = rdlane64(cb, 0); cf = rdlane64(cf, 0); }
-            // a window with fewer than six read bases opposite it is not worth its 8 bytes per candidate (off the read altogether: no load either way)
-            if (popc64(ma) < 12) ma = 0;
-            if (popc64(mb) < 12) mb = 0;
-            if (popc64(mf) < 12) mf = 0;
-            const bool has_a = ma != 0, has_b = mb != 0, has_f = mf != 0;
+            const uint32_t h = l_hcs & 0xffffu, chain = (l_hcs >> 16) & 1u;
+            // The index keeps six flank words per entry (the 96 bases after the seed, the 96 before it) and the entry's own 16 bases. Up to four
+            // windows are tested per candidate, the ones with the most read bases opposite them first (after0 >= after1 >= after2, likewise
+            // before: a merge of two descending runs). When those four cover the whole read outside the seed -- every read of up to 100 bases
+            // at K = 16, most seeds of longer ones -- the test IS CountMismatch* (align.h:118-131, 199-239; the count is a sum over disjoint
+            // windows): such a list is `full`, its survivors carry their exact count and never touch the reference.
+            const uint32_t nA = rc.len - h - cx.K, nB = h;
+            uint64_t wr[4], wm[4], wc[4];
+            uint32_t wsid[4], covered = 0;
+            {
+                uint32_t ia = 0, ib = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t ca = ia < 3 && nA > 32 * ia ? (nA - 32 * ia < 32 ? nA - 32 * ia : 32u) : 0;
+                    const uint32_t cb = ib < 3 && nB > 32 * ib ? (nB - 32 * ib < 32 ? nB - 32 * ib : 32u) : 0;
+                    int pos;
+                    if (ca >= cb) { covered += ca; pos = (int)(h + cx.K + 32 * ia); wsid[w] = 2 * ia; ia += ca != 0; }
+                    else { covered += cb; pos = (int)h - 32 * (int)(ib + 1); wsid[w] = 2 * ib + 1; ib++; }
+                    plane_window3<NWT, NEWRULE>(L.q[chain], pos, wr[w], wm[w], wc[w]);
+                    wr[w] = rdlane64(wr[w], 0); wm[w] = rdlane64(wm[w], 0);
+                    wc[w] = NEWRULE ? rdlane64(wc[w], 0) : 0;
+                    if (ca == 0 && cb == 0) wm[w] = 0;
+                }
+            }
+            const bool full = covered == nA + nB;
+            // the seed's own bases: the k-mer code folds letters 01 and 11 (Param::XT, param.h:107-116), so an entry of this list may differ from
+            // the read there; its 16 bases are fetched only when one of the two letters would count as a mismatch against a read base of the seed
+            uint64_t sr = 0, sm = 0, sc = 0;
+            bool need_seed = false;
+            if (full) {
+                plane_window3<NWT, NEWRULE>(L.q[chain], (int)h, sr, sm, sc);
+                sr = rdlane64(sr, 0); sm = rdlane64(sm, 0) & (~0ULL << (64 - 2 * cx.K));
+                sc = NEWRULE ? rdlane64(sc, 0) : 0;
+                const uint64_t fold = (sr & kPairLo) << 1;
+                need_seed = (pair_mask(cmp_word<NEWRULE>(sr, sc, sr & ~fold) | cmp_word<NEWRULE>(sr, sc, sr | fold)) & pair_mask(sm)) != 0;
+            } else {
+                // not exact anyway: a window with fewer than six read bases opposite it is not worth its 8 bytes per candidate, nor is a fourth one
+                wm[3] = 0;
+#pragma unroll
+                for (int w = 0; w < 3; w++)
+                    if (popc64(wm[w]) < 12) wm[w] = 0;
+            }
+            const bool has0 = wm[0] != 0, has1 = wm[1] != 0, has2 = wm[2] != 0, has3 = wm[3] != 0;
             const uint32_t *Lc = cx.locs + l_off;
-            const uint64_t *Fa = cx.flank_a + l_off, *Fb = Fa + stride, *Ff = Fa + (2ULL + side) * stride;
-            // Two stages of loads per chunk, each issued ahead of its use: the two near windows for every candidate; the far window and the
-            // location only for the lanes the near windows left alive -- a 128-byte line of either is fetched only if one of its 16 (32)
-            // candidates is (40 % of those lines are not, on the hg38-like stand-in: the kernel is bound by HBM bytes).
+            const uint64_t *F0 = cx.flank_a + l_off + wsid[0] * stride, *F1 = cx.flank_a + l_off + wsid[1] * stride, *F2 = cx.flank_a + l_off + wsid[2] * stride,
+                           *F3 = cx.flank_a + l_off + wsid[3] * stride;
+            const uint32_t *Sw = need_seed ? COLDP(const uint32_t, seedw) + l_off : nullptr;
+            // Two stages of loads per chunk, each issued ahead of its use: the two widest windows for every candidate; the other windows, the
+            // seed word and the location only for the lanes the first two left alive -- a 128-byte line of those is fetched only if one of
+            // its 16 (32) candidates is (40 % of those lines are not, on the hg38-like stand-in: the kernel is bound by HBM bytes).
             struct S1 { uint64_t a, b; };
-            struct S2 { uint32_t loc; uint64_t f; };
+            struct S2 { uint32_t loc, sw; uint64_t c, d; };
             auto jj_of = [&](uint32_t p) { uint32_t jj = l_jj0 + p; return jj >= l_m ? jj - l_m : jj; };
             // (the stream is read once: non-temporal loads keep it from pushing the index tables and reference lines out of the caches, +1.5 %;
             // the same hint on the survivors' reference words, five loads into one line, cost 20 %)
@@ -1253,21 +1289,23 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 const uint32_t p = p0 + (uint32_t)lane;
                 if (p < l_m) {
                     const uint32_t jj = jj_of(p);
-                    if (has_a) c.a = __builtin_nontemporal_load(&Fa[jj]);
-                    if (has_b) c.b = __builtin_nontemporal_load(&Fb[jj]);
+                    if (has0) c.a = __builtin_nontemporal_load(&F0[jj]);
+                    if (has1) c.b = __builtin_nontemporal_load(&F1[jj]);
                 }
                 return c;
             };
             auto eval1 = [&](const S1 &c, uint32_t p0, uint32_t &lb) {
-                lb = rc.n_count + XM64(cmp_word<NEWRULE>(ra, ca, c.a) & ma) + XM64(cmp_word<NEWRULE>(rb, cb, c.b) & mb);
+                lb = rc.n_count + XM64(cmp_word<NEWRULE>(wr[0], wc[0], c.a) & wm[0]) + XM64(cmp_word<NEWRULE>(wr[1], wc[1], c.b) & wm[1]);
                 return p0 + (uint32_t)lane < l_m && lb <= st.thr;
             };
             auto issue2 = [&](uint32_t p0, bool want) {
-                S2 c = {0, 0};
+                S2 c = {0, 0, 0, 0};
                 if (want) {
                     const uint32_t jj = jj_of(p0 + (uint32_t)lane);
                     c.loc = __builtin_nontemporal_load(&Lc[jj]);
-                    if (has_f) c.f = __builtin_nontemporal_load(&Ff[jj]);
+                    if (has2) c.c = __builtin_nontemporal_load(&F2[jj]);
+                    if (has3) c.d = __builtin_nontemporal_load(&F3[jj]);
+                    if (need_seed) c.sw = __builtin_nontemporal_load(&Sw[jj]);
                 }
                 return c;
             };
@@ -1278,12 +1316,14 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
             n1 = n1b;
             n1b = issue1(128);
             for (uint32_t p0 = 0; p0 < l_m && !stop; p0 += 64) {
-                // in flight: c2 = the far words / locations of this chunk, n1 / n1b = the near words of the next two
+                // in flight: c2 = the stage-two words / locations of this chunk, n1 / n1b = the stage-one words of the next two
                 const S1 nn1 = issue1(p0 + 192);
                 uint32_t lb_next;
                 const bool alive_next = eval1(n1, p0 + 64, lb_next);
                 const S2 n2 = issue2(p0 + 64, alive_next);
-                const bool alive = alive_cur && lb_cur + XM64(cmp_word<NEWRULE>(rf, cf, c2.f) & mf) <= st.thr;
+                const uint32_t mm = lb_cur + XM64(cmp_word<NEWRULE>(wr[2], wc[2], c2.c) & wm[2]) + XM64(cmp_word<NEWRULE>(wr[3], wc[3], c2.d) & wm[3]) +
+                                    XM64(cmp_word<NEWRULE>(sr, sc, (uint64_t)c2.sw << 32) & (need_seed ? sm : 0ULL));
+                const bool alive = alive_cur && mm <= st.thr;
 #ifdef BASAL_PHASE_TIMING  // long-list chunks; lanes alive after the two near windows; 16-lane groups (128-byte lines of the far words) with such a lane; survivors
                 {
                     const uint64_t ab = ballot(alive_cur);
@@ -1298,7 +1338,7 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                     if (alive) {
                         SurvEnt sv;
                         sv.loc = c2.loc - h;
-                        sv.meta = (uint32_t)(jj_of(p0 + (uint32_t)lane) >= l_nfwd) | (chain << 1);
+                        sv.meta = (uint32_t)(jj_of(p0 + (uint32_t)lane) >= l_nfwd) | (chain << 1) | (full ? 4u | (mm << 3) : 0u);
                         L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
                     }
                     nsurv += (uint32_t)__popcll(mk);
@@ -1986,7 +2026,7 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
-    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_tables); hipFree(c->d_scratch);
+    hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_seedw); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_names); hipFree(c->d_name_off);
     hipFree(c->d_pe_pairs); hipFree(c->d_pe_recs); hipFree(c->d_pe_work); hipFree(c->d_pe_misc);
     hipFree(c->d_counter);
@@ -2149,7 +2189,7 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         }
         cx.win2_min_T = c->max_kmer_num >= min_cut ? min_T : 0xFFFFFFFFu;
     }
-    cx.flank_a = c->d_flank_a; cx.flank_b = c->d_flank_b;
+    cx.flank_a = c->d_flank_a; cx.flank_b = c->d_flank_b; cx.seedw = c->d_seedw;
     cx.K = c->p.seed_size; cx.I = c->p.index_interval; cx.max_num_hits = c->p.max_num_hits; cx.chains = c->p.chains;
     cx.randseed = c->p.randseed; cx.gap = c->p.gap; cx.gap_edge = c->p.gap_edge; cx.n_mis = c->p.n_mis;
     cx.stream_mode = (uint32_t)stream_mode; cx.report_repeat_hits = c->p.report_repeat_hits;

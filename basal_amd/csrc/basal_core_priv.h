@@ -34,6 +34,7 @@ struct basal_core {
     uint32_t ncontig = 0;
     uint32_t *d_koff = nullptr, *d_knfwd = nullptr, *d_locs = nullptr;
     uint64_t *d_flank_a = nullptr, *d_flank_b = nullptr;  // per index entry: the 32 reference bases after / before the seed
+    uint32_t *d_seedw = nullptr;  // heavy cores: per index entry its own 16 bases
     uint64_t nlocs = 0;
     uint32_t total_kmers = 0, max_kmer_num = 0;
     bool have_ref = false, have_index = false;

@@ -83,33 +83,38 @@ __device__ __forceinline__ uint64_t flank_word(const uint64_t *__restrict__ x, u
     const uint64_t *w = x + (p >> 5);
     return a ? (w[0] << a) | (w[1] >> (64 - a)) : w[0];
 }
-// far != 0 (cores whose index keeps long lists, basal_core::heavy): two more words per entry, the 32 bases beyond each near flank --
-// [e+K+32, e+K+64) at fa[2 * stride + i], [e-64, e-32) at fa[3 * stride + i] (the reference keeps 400 margin words either side)
+// far != 0 (cores whose index keeps long lists, basal_core::heavy): four more words per entry, the 64 bases beyond each near flank --
+// [e+K+32, e+K+64) at fa[2 * stride + i], [e-64, e-32) at [3], [e+K+64, e+K+96) at [4], [e-96, e-64) at [5] -- and the entry's own 16 bases
+// [e, e+16) in seedw[i] (top bits first): with those a long list's candidates are scored from the coalesced stream alone (basal_core.hip,
+// heavy_mode). The reference keeps 400 margin words either side.
 __device__ __forceinline__ void store_flanks(const uint64_t *__restrict__ x, uint32_t g, uint32_t K, unsigned long long i, unsigned long long stride, int far,
-                                             uint64_t *__restrict__ fa) {
+                                             uint64_t *__restrict__ fa, uint32_t *__restrict__ seedw) {
     fa[i] = flank_word(x, g + K);
     fa[stride + i] = flank_word(x, g - 32);
     if (far) {
         fa[2 * stride + i] = flank_word(x, g + K + 32);
         fa[3 * stride + i] = flank_word(x, g - 64);
+        fa[4 * stride + i] = flank_word(x, g + K + 64);
+        fa[5 * stride + i] = flank_word(x, g - 96);
+        seedw[i] = (uint32_t)(flank_word(x, g) >> 32);
     }
 }
 __global__ __launch_bounds__(256) void fill_flanks(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const uint32_t *__restrict__ koff,
                                                    const uint32_t *__restrict__ knfwd, const uint32_t *__restrict__ locs, uint32_t total_kmers, uint32_t K,
-                                                   unsigned long long stride, int far, uint64_t *__restrict__ fa) {
+                                                   unsigned long long stride, int far, uint64_t *__restrict__ fa, uint32_t *__restrict__ seedw) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total_kmers) return;
     uint32_t b = koff[k], e = koff[k + 1], nf = knfwd[k];
-    for (uint32_t i = b; i < e; i++) store_flanks((i - b) >= nf ? xr : xf, locs[i], K, i, stride, far, fa);
+    for (uint32_t i = b; i < e; i++) store_flanks((i - b) >= nf ? xr : xf, locs[i], K, i, stride, far, fa, seedw);
 }
 
 // The same words, one thread per index ENTRY: right after the GPU build's sort the entry's strand is bit 0 of its sorted key,
 // so no per-k-mer list walk is needed (coalesced location reads and flank stores; lists of 10^4 entries cost what 10^4 short ones do).
 __global__ __launch_bounds__(256) void fill_flanks_sorted(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const uint32_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ locs, unsigned long long nlocs, uint32_t K, unsigned long long stride,
-                                                          int far, uint64_t *__restrict__ fa) {
+                                                          int far, uint64_t *__restrict__ fa, uint32_t *__restrict__ seedw) {
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nlocs; i += (unsigned long long)gridDim.x * blockDim.x)
-        store_flanks((keys[i] & 1u) ? xr : xf, locs[i], K, i, stride, far, fa);
+        store_flanks((keys[i] & 1u) ? xr : xf, locs[i], K, i, stride, far, fa, seedw);
 }
 
 // ---- GAP cores (-g > 0): the flanks as BIT PLANES, 64 bases each side ----------------------------------------------------------------------
@@ -187,16 +192,19 @@ int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys) {
         c->heavy = e ? atoi(e) != 0 : c->max_kmer_num >= 32768;
     }
     const int far = c->heavy ? 1 : 0;
-    HIP_TRYI(hipMalloc(&c->d_flank_a, (far ? 4 : 2) * stride * 8));
+    HIP_TRYI(hipMalloc(&c->d_flank_a, (far ? 6 : 2) * stride * 8));
     c->d_flank_b = c->d_flank_a + stride;
+    hipFree(c->d_seedw);
+    c->d_seedw = nullptr;
+    if (far) HIP_TRYI(hipMalloc(&c->d_seedw, stride * 4));
     if (d_sorted_keys && c->nlocs) {
         unsigned long long want = (c->nlocs + 255) / 256;
         uint32_t grid = (uint32_t)std::min<unsigned long long>(want, (unsigned long long)c->prop.multiProcessorCount * 64);
         hipLaunchKernelGGL(fill_flanks_sorted, dim3(grid), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], d_sorted_keys, c->d_locs, (unsigned long long)c->nlocs,
-                           c->p.seed_size, stride, far, c->d_flank_a);
+                           c->p.seed_size, stride, far, c->d_flank_a, c->d_seedw);
     } else
         hipLaunchKernelGGL(fill_flanks, dim3((c->total_kmers + 255) / 256), dim3(256), 0, 0, c->d_xref[0], c->d_xref[1], c->d_koff, c->d_knfwd, c->d_locs,
-                           c->total_kmers, c->p.seed_size, stride, far, c->d_flank_a);
+                           c->total_kmers, c->p.seed_size, stride, far, c->d_flank_a, c->d_seedw);
     HIP_TRYI(hipGetLastError());
     HIP_TRYI(hipDeviceSynchronize());
     return BASAL_OK;
