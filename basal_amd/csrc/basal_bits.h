@@ -59,6 +59,21 @@ BASAL_HD uint32_t myrand(uint32_t index, uint32_t randseed) {
     return (uint32_t)v;
 }
 
+// The even-numbered bits of x (bit 0, 2, 4 ...) packed into 32 bits.
+BASAL_HD uint32_t even_bits(uint64_t x) {
+    x &= kPairLo;
+    x = (x | (x >> 1)) & 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    return (uint32_t)(x | (x >> 16));
+}
+// A 32-base word as two bit planes: the high bits of the 32 base codes in the upper half, the low bits in the lower (base 0 on top in both).
+// The flank words of cores whose index keeps long lists are stored this way (basal_index.hip), so that the stream test needs no shifts.
+BASAL_HD uint64_t split_planes(uint64_t w) { return ((uint64_t)even_bits(w >> 1) << 32) | even_bits(w); }
+// 16 bases (a 32-bit word) likewise: high bits in the upper 16, low bits in the lower 16
+BASAL_HD uint32_t split_planes16(uint32_t w) { return (even_bits(w >> 1) << 16) | even_bits(w); }
+
 // Conversion-tolerant comparison of one 32-base word (the body of CountMismatch, align.h:126-128,
 // and of CountMismatch_new, align.h:210-219): non-zero pairs of the result are mismatches.
 // rw = read bases, cw = read "is a convert-to base" plane, s = reference bases (same frame).

@@ -1151,6 +1151,46 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
     }
 }
 
+// A window of the HEAVY kernels' stream test. The flank words of a core that keeps long lists are stored as bit planes (basal_bits.h
+// split_planes: the high bits of the 32 base codes in the upper half, the low bits in the lower), and what depends on the read alone is folded
+// into four 32-bit words, so that cmp_word's rule (basal_bits.h; CountMismatch / CountMismatch_new, align.h:126-128, 210-219) costs a
+// candidate four (old rule) or six (new rule) instructions per 32 bases and no shifts. With th / tl = the planes of s ^ r:
+//   old rule: a mismatch unless s == r, or s == 01 and r == 11 (then th = 1, tl = 0):  (th & ~[r == 11]) | tl
+//   new rule: a mismatch unless s == r, or s == 01 and the read base is convert-tolerant (high bit of the convert-to plane clear)
+// rh, rl = the read's planes; m = valid read bases (the valid plane holds 00 or 11 per base: basal_core_create checks reg_alphabet for
+// that); x = old rule: m & ~[r == 11] / new rule: the tolerant bases.
+struct WinP { uint32_t rh, rl, x, m; };
+template <bool NEWRULE>
+__device__ __forceinline__ WinP win_make(uint64_t r, uint64_t valid, uint64_t c) {
+    WinP k;
+    k.rh = even_bits(r >> 1); k.rl = even_bits(r);
+    k.m = even_bits(valid >> 1);
+    k.x = NEWRULE ? even_bits(~c >> 1) : k.m & ~(k.rh & k.rl);
+    return k;
+}
+template <bool NEWRULE>
+__device__ __forceinline__ uint32_t win_count(const WinP &k, uint64_t s) {
+    const uint32_t sh = (uint32_t)(s >> 32), sl = (uint32_t)s;
+    if (!NEWRULE) return (uint32_t)__popc(((sh ^ k.rh) & k.x) | ((sl ^ k.rl) & k.m));
+    return (uint32_t)__popc(((sh ^ k.rh) | (sl ^ k.rl)) & k.m & ~(~sh & sl & k.x));
+}
+// the same for the 16 bases of a seed (basal_bits.h split_planes16: high bits in bits 16-31, low bits in bits 0-15); r = both planes of the read
+struct WinP16 { uint32_t r, x, m; };
+template <bool NEWRULE>
+__device__ __forceinline__ WinP16 win_make16(uint32_t r, uint32_t valid, uint32_t c) {
+    WinP16 k;
+    k.r = split_planes16(r);
+    k.m = even_bits(valid >> 1);
+    k.x = NEWRULE ? even_bits(~c >> 1) : k.m & ~((k.r >> 16) & k.r);
+    return k;
+}
+template <bool NEWRULE>
+__device__ __forceinline__ uint32_t win_count16(const WinP16 &k, uint32_t s) {
+    const uint32_t t = s ^ k.r;
+    if (!NEWRULE) return (uint32_t)__popc(((t >> 16) & k.x) | (t & k.m));
+    return (uint32_t)__popc(((t >> 16) | t) & k.m & ~(~(s >> 16) & s & k.x));
+}
+
 // the candidates in L.surv[0 .. min(nsurv, 64)): all their reference words in one round trip, exact count (CountMismatch*), bulk bookkeeping
 template <int NWT, bool NEWRULE, class LDS>
 __device__ bool heavy_flush(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t mode, uint32_t &nsurv, uint32_t r, int lane PH_PARAM) {
@@ -1210,8 +1250,9 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 SurvEnt sv = {0, 0};
                 if (active) {
                     const uint32_t ei = cur.ei, hcs = L.ent[ei].hcs, e_nfwd = L.ent[ei].nfwd;
-                    const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm, e_fc = NEWRULE ? L.ent[ei].fc : 0;
-                    alive = rc.n_count + XM64(cmp_word<NEWRULE>(e_fr, e_fc, cur.f) & e_fm) <= st.thr;
+                    const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm;  // (as planes: process_read stores them that way for the HEAVY kernels)
+                    const WinP k = {(uint32_t)(e_fr >> 32), (uint32_t)e_fr, (uint32_t)(e_fm >> 32), (uint32_t)e_fm};
+                    alive = rc.n_count + win_count<NEWRULE>(k, cur.f) <= st.thr;
                     sv.loc = cur.loc_raw - (hcs & 0xffffu);
                     sv.meta = (uint32_t)(cur.jj >= e_nfwd) | (((hcs >> 16) & 1u) << 1);
                 }
@@ -1236,7 +1277,7 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
             // at K = 16, most seeds of longer ones -- the test IS CountMismatch* (align.h:118-131, 199-239; the count is a sum over disjoint
             // windows): such a list is `full`, its survivors carry their exact count and never touch the reference.
             const uint32_t nA = rc.len - h - cx.K, nB = h;
-            uint64_t wr[4], wm[4], wc[4];
+            WinP wk[4];
             uint32_t wsid[4], covered = 0;
             {
                 uint32_t ia = 0, ib = 0;
@@ -1247,38 +1288,41 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                     int pos;
                     if (ca >= cb) { covered += ca; pos = (int)(h + cx.K + 32 * ia); wsid[w] = 2 * ia; ia += ca != 0; }
                     else { covered += cb; pos = (int)h - 32 * (int)(ib + 1); wsid[w] = 2 * ib + 1; ib++; }
-                    plane_window3<NWT, NEWRULE>(L.q[chain], pos, wr[w], wm[w], wc[w]);
-                    wr[w] = rdlane64(wr[w], 0); wm[w] = rdlane64(wm[w], 0);
-                    wc[w] = NEWRULE ? rdlane64(wc[w], 0) : 0;
-                    if (ca == 0 && cb == 0) wm[w] = 0;
+                    uint64_t wr, wm, wc;
+                    plane_window3<NWT, NEWRULE>(L.q[chain], pos, wr, wm, wc);
+                    wk[w] = win_make<NEWRULE>(rdlane64(wr, 0), ca == 0 && cb == 0 ? 0 : rdlane64(wm, 0), NEWRULE ? rdlane64(wc, 0) : 0);
                 }
             }
             const bool full = covered == nA + nB;
             // the seed's own bases: the k-mer code folds letters 01 and 11 (Param::XT, param.h:107-116), so an entry of this list may differ from
             // the read there; its 16 bases are fetched only when one of the two letters would count as a mismatch against a read base of the seed
-            uint64_t sr = 0, sm = 0, sc = 0;
+            WinP16 sk = {0, 0, 0};
             bool need_seed = false;
             if (full) {
+                uint64_t sr, sm, sc;
                 plane_window3<NWT, NEWRULE>(L.q[chain], (int)h, sr, sm, sc);
-                sr = rdlane64(sr, 0); sm = rdlane64(sm, 0) & (~0ULL << (64 - 2 * cx.K));
-                sc = NEWRULE ? rdlane64(sc, 0) : 0;
-                const uint64_t fold = (sr & kPairLo) << 1;
-                need_seed = (pair_mask(cmp_word<NEWRULE>(sr, sc, sr & ~fold) | cmp_word<NEWRULE>(sr, sc, sr | fold)) & pair_mask(sm)) != 0;
+                sk = win_make16<NEWRULE>((uint32_t)(rdlane64(sr, 0) >> 32), (uint32_t)((rdlane64(sm, 0) & (~0ULL << (64 - 2 * cx.K))) >> 32),
+                                         NEWRULE ? (uint32_t)(rdlane64(sc, 0) >> 32) : 0);
+                const uint32_t fold = (sk.r & 0xffffu) << 16;
+                need_seed = (win_count16<NEWRULE>(sk, sk.r & ~fold) | win_count16<NEWRULE>(sk, sk.r | fold)) != 0;
             } else {
                 // not exact anyway: a window with fewer than six read bases opposite it is not worth its 8 bytes per candidate, nor is a fourth one
-                wm[3] = 0;
+                wk[3].m = wk[3].x = 0;
 #pragma unroll
                 for (int w = 0; w < 3; w++)
-                    if (popc64(wm[w]) < 12) wm[w] = 0;
+                    if (__popc(wk[w].m) < 6) wk[w].m = wk[w].x = 0;
             }
-            const bool has0 = wm[0] != 0, has1 = wm[1] != 0, has2 = wm[2] != 0, has3 = wm[3] != 0;
+            const bool has0 = wk[0].m != 0, has1 = wk[1].m != 0, has2 = wk[2].m != 0, has3 = wk[3].m != 0;
             const uint32_t *Lc = cx.locs + l_off;
             const uint64_t *F0 = cx.flank_a + l_off + wsid[0] * stride, *F1 = cx.flank_a + l_off + wsid[1] * stride, *F2 = cx.flank_a + l_off + wsid[2] * stride,
                            *F3 = cx.flank_a + l_off + wsid[3] * stride;
             const uint32_t *Sw = need_seed ? COLDP(const uint32_t, seedw) + l_off : nullptr;
             // Two stages of loads per chunk, each issued ahead of its use: the two widest windows for every candidate; the other windows, the
             // seed word and the location only for the lanes the first two left alive -- a 128-byte line of those is fetched only if one of
-            // its 16 (32) candidates is (40 % of those lines are not, on the hg38-like stand-in: the kernel is bound by HBM bytes).
+            // its 16 (32) candidates is (half of those lines are not, on the hg38-like stand-in).
+            // (Loads under branches make the compiler wait for all loads in flight at the first use of any, s_waitcnt vmcnt(0); issuing every
+            // load from every lane -- idle lanes reading a line that is cached anyway -- gave exact wait counts and a slower kernel, 150 -> 157 ms
+            // per 10 M reads: the address selects cost more vector instructions than the deeper pipeline won, with six waves per SIMD to switch to.)
             struct S1 { uint64_t a, b; };
             struct S2 { uint32_t loc, sw; uint64_t c, d; };
             auto jj_of = [&](uint32_t p) { uint32_t jj = l_jj0 + p; return jj >= l_m ? jj - l_m : jj; };
@@ -1295,7 +1339,7 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 return c;
             };
             auto eval1 = [&](const S1 &c, uint32_t p0, uint32_t &lb) {
-                lb = rc.n_count + XM64(cmp_word<NEWRULE>(wr[0], wc[0], c.a) & wm[0]) + XM64(cmp_word<NEWRULE>(wr[1], wc[1], c.b) & wm[1]);
+                lb = rc.n_count + win_count<NEWRULE>(wk[0], c.a) + win_count<NEWRULE>(wk[1], c.b);
                 return p0 + (uint32_t)lane < l_m && lb <= st.thr;
             };
             auto issue2 = [&](uint32_t p0, bool want) {
@@ -1321,8 +1365,10 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 uint32_t lb_next;
                 const bool alive_next = eval1(n1, p0 + 64, lb_next);
                 const S2 n2 = issue2(p0 + 64, alive_next);
-                const uint32_t mm = lb_cur + XM64(cmp_word<NEWRULE>(wr[2], wc[2], c2.c) & wm[2]) + XM64(cmp_word<NEWRULE>(wr[3], wc[3], c2.d) & wm[3]) +
-                                    XM64(cmp_word<NEWRULE>(sr, sc, (uint64_t)c2.sw << 32) & (need_seed ? sm : 0ULL));
+                uint32_t mm = lb_cur;
+                if (has2) mm += win_count<NEWRULE>(wk[2], c2.c);
+                if (has3) mm += win_count<NEWRULE>(wk[3], c2.d);
+                if (need_seed) mm += win_count16<NEWRULE>(sk, c2.sw);
                 const bool alive = alive_cur && mm <= st.thr;
 #ifdef BASAL_PHASE_TIMING  // long-list chunks; lanes alive after the two near windows; 16-lane groups (128-byte lines of the far words) with such a lane; survivors
                 {
@@ -1465,7 +1511,10 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
             if ((unsigned long long)e_off + e_m > COLD(nlocs)) e_off = guard_u32(cx, G_LOCS, e_off + e_m, 0, r);
             SeedEntT<GAP> e;
             e.off = e_off; e.m = e_m; e.nfwd = e_nfwd; e.jj0 = e_jj0; e.pre = inc - e_m; e.hcs = e_h | (e_chain << 16) | (side << 17);
-            if constexpr (!GAP) { e.fr = wr; e.fm = wm; e.fc = wc; }
+            if constexpr (HEAVY) {  // the flank words of such a core are bit planes: the read's window likewise (win_make)
+                const WinP k = win_make<NEWRULE>(wr, wm, wc);
+                e.fr = (uint64_t)k.rh << 32 | k.rl; e.fm = (uint64_t)k.x << 32 | k.m; e.fc = 0;
+            } else if constexpr (!GAP) { e.fr = wr; e.fm = wm; e.fc = wc; }
             L.ent[lane] = e;
             if constexpr (GAP) {
                 const int pl = side ? (int)e_h - 64 : (int)(e_h + cx.K), ps = side ? (int)(e_h + cx.K) : (int)e_h - 32;
@@ -1994,6 +2043,8 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
         g_err = "parameter out of range (seed_size 10..16, index_interval 1..16, gap<=3, 1<=max_num_hits<=1000, chains 0..2)";
         return BASAL_EINVAL;
     }
+    for (int i = 0; i < 256; i++)  // (the stream tests read "a valid base" as one bit per base)
+        if (p->reg_alphabet[i] != 0 && p->reg_alphabet[i] != 3) { g_err = "reg_alphabet: every entry must be 0 or 3 (param.cpp:130-139)"; return BASAL_EINVAL; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_err = "no HIP device: the BASAL core needs an MI355X (gfx950); there is no CPU fallback"; return BASAL_EDEVICE; }
     if (device < 0 || device >= ndev) { g_err = "bad device ordinal"; return BASAL_EINVAL; }

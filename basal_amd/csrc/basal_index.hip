@@ -89,15 +89,19 @@ __device__ __forceinline__ uint64_t flank_word(const uint64_t *__restrict__ x, u
 // heavy_mode). The reference keeps 400 margin words either side.
 __device__ __forceinline__ void store_flanks(const uint64_t *__restrict__ x, uint32_t g, uint32_t K, unsigned long long i, unsigned long long stride, int far,
                                              uint64_t *__restrict__ fa, uint32_t *__restrict__ seedw) {
-    fa[i] = flank_word(x, g + K);
-    fa[stride + i] = flank_word(x, g - 32);
-    if (far) {
-        fa[2 * stride + i] = flank_word(x, g + K + 32);
-        fa[3 * stride + i] = flank_word(x, g - 64);
-        fa[4 * stride + i] = flank_word(x, g + K + 64);
-        fa[5 * stride + i] = flank_word(x, g - 96);
-        seedw[i] = (uint32_t)(flank_word(x, g) >> 32);
+    if (!far) {
+        fa[i] = flank_word(x, g + K);
+        fa[stride + i] = flank_word(x, g - 32);
+        return;
     }
+    // (as bit planes, basal_bits.h split_planes: the HEAVY kernels compare a window in four instructions that way)
+    fa[i] = split_planes(flank_word(x, g + K));
+    fa[stride + i] = split_planes(flank_word(x, g - 32));
+    fa[2 * stride + i] = split_planes(flank_word(x, g + K + 32));
+    fa[3 * stride + i] = split_planes(flank_word(x, g - 64));
+    fa[4 * stride + i] = split_planes(flank_word(x, g + K + 64));
+    fa[5 * stride + i] = split_planes(flank_word(x, g - 96));
+    seedw[i] = split_planes16((uint32_t)(flank_word(x, g) >> 32));
 }
 __global__ __launch_bounds__(256) void fill_flanks(const uint64_t *__restrict__ xf, const uint64_t *__restrict__ xr, const uint32_t *__restrict__ koff,
                                                    const uint32_t *__restrict__ knfwd, const uint32_t *__restrict__ locs, uint32_t total_kmers, uint32_t K,
