@@ -231,7 +231,7 @@ template <bool HEAVY>
 struct HeavyLds {};
 template <>
 struct HeavyLds<true> {
-    SurvEnt surv[128];    // meta = reference strand | read chain << 1 | counted exactly already << 2 | that count << 3
+    SurvEnt surv[128];    // meta = reference strand | read chain << 1; counted from the stream already: | 4 | the count << 3 | the seed's read offset << 11, and loc = the index entry
     uint32_t bloom[128];  // a 4096-bit Bloom filter over the keys of ALL stored hits of the read (bulk_add)
     uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
@@ -1200,8 +1200,9 @@ __device__ bool heavy_flush(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
     if (active) {
         const SurvEnt sv = L.surv[lane];
         loc = sv.loc; strand = sv.meta & 1u; chain = (sv.meta >> 1) & 1u;
+        if (sv.meta & 4u) loc = cx.locs[loc] - (sv.meta >> 11);  // counted from the stream: sv.loc is the index entry, bits 11.. its seed's read offset
         if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
-        if (sv.meta & 4u) mm = sv.meta >> 3;  // a `full` long list's candidate: counted exactly from the stream (heavy_mode)
+        if (sv.meta & 4u) mm = (sv.meta >> 3) & 0xffu;  // a `full` long list's candidate: counted exactly from the stream (heavy_mode)
         else {
             const uint32_t off2 = (loc & 31) * 2, nw = (rc.len + (loc & 31) + 31) / 32;
             mm = count_mismatch<NWT, NEWRULE>((strand ? cx.xref[1] : cx.xref[0]) + (loc >> 5), L.q[chain], off2, nw, st.thr, rc.n_count);
@@ -1346,7 +1347,7 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 S2 c = {0, 0, 0, 0};
                 if (want) {
                     const uint32_t jj = jj_of(p0 + (uint32_t)lane);
-                    c.loc = __builtin_nontemporal_load(&Lc[jj]);
+                    if (!full) c.loc = __builtin_nontemporal_load(&Lc[jj]);  // (a full list's survivors fetch theirs when they are scored: 1 in 7 of these lanes)
                     if (has2) c.c = __builtin_nontemporal_load(&F2[jj]);
                     if (has3) c.d = __builtin_nontemporal_load(&F3[jj]);
                     if (need_seed) c.sw = __builtin_nontemporal_load(&Sw[jj]);
@@ -1383,8 +1384,9 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
                 if (mk) {
                     if (alive) {
                         SurvEnt sv;
-                        sv.loc = c2.loc - h;
-                        sv.meta = (uint32_t)(jj_of(p0 + (uint32_t)lane) >= l_nfwd) | (chain << 1) | (full ? 4u | (mm << 3) : 0u);
+                        const uint32_t jj = jj_of(p0 + (uint32_t)lane);
+                        sv.loc = full ? l_off + jj : c2.loc - h;
+                        sv.meta = (uint32_t)(jj >= l_nfwd) | (chain << 1) | (full ? 4u | ((mm & 0xffu) << 3) | (h << 11) : 0u);
                         L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
                     }
                     nsurv += (uint32_t)__popcll(mk);
