@@ -207,6 +207,9 @@ __device__ __forceinline__ uint64_t bits64(const uint64_t *pl, int start) {
 #ifndef WORK_CHUNK
 #define WORK_CHUNK 8  // reads a wave takes from the queue per atomic
 #endif
+#ifndef LONG_WD
+#define LONG_WD 2  // HEAVY kernels: chunks of 64 candidates of a long list per memory round trip (heavy_mode)
+#endif
 
 struct SurvEnt {  // a gap-eligible or still-alive candidate of the stream
     uint32_t loc;   // alignment start (bounds-checked)
@@ -1324,76 +1327,80 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
             // (Loads under branches make the compiler wait for all loads in flight at the first use of any, s_waitcnt vmcnt(0); issuing every
             // load from every lane -- idle lanes reading a line that is cached anyway -- gave exact wait counts and a slower kernel, 150 -> 157 ms
             // per 10 M reads: the address selects cost more vector instructions than the deeper pipeline won, with six waves per SIMD to switch to.)
-            struct S1 { uint64_t a, b; };
-            struct S2 { uint32_t loc, sw; uint64_t c, d; };
+            // LONG_WD chunks of 64 candidates per iteration, one exposed memory round trip for all of them: the stage-one words of an iteration
+            // are requested during the one before; its stage-two words go out as soon as stage one has been looked at, the next iteration's
+            // stage-one words right behind them, and the wave waits once for both. (A wave alone on the GPU -- the longest reads at the end of
+            // a launch -- is bound by exactly these round trips.)
+            constexpr int WD = NWT == 4 ? LONG_WD : 1;  // (the longer reads' kernels have no registers to spare)
+            struct S1 { uint64_t a[WD], b[WD]; };
+            struct S2 { uint32_t loc[WD], sw[WD]; uint64_t c[WD], d[WD]; };
             auto jj_of = [&](uint32_t p) { uint32_t jj = l_jj0 + p; return jj >= l_m ? jj - l_m : jj; };
             // (the stream is read once: non-temporal loads keep it from pushing the index tables and reference lines out of the caches, +1.5 %;
             // the same hint on the survivors' reference words, five loads into one line, cost 20 %)
             auto issue1 = [&](uint32_t p0) {
-                S1 c = {0, 0};
-                const uint32_t p = p0 + (uint32_t)lane;
-                if (p < l_m) {
-                    const uint32_t jj = jj_of(p);
-                    if (has0) c.a = __builtin_nontemporal_load(&F0[jj]);
-                    if (has1) c.b = __builtin_nontemporal_load(&F1[jj]);
-                }
-                return c;
-            };
-            auto eval1 = [&](const S1 &c, uint32_t p0, uint32_t &lb) {
-                lb = rc.n_count + win_count<NEWRULE>(wk[0], c.a) + win_count<NEWRULE>(wk[1], c.b);
-                return p0 + (uint32_t)lane < l_m && lb <= st.thr;
-            };
-            auto issue2 = [&](uint32_t p0, bool want) {
-                S2 c = {0, 0, 0, 0};
-                if (want) {
-                    const uint32_t jj = jj_of(p0 + (uint32_t)lane);
-                    if (!full) c.loc = __builtin_nontemporal_load(&Lc[jj]);  // (a full list's survivors fetch theirs when they are scored: 1 in 7 of these lanes)
-                    if (has2) c.c = __builtin_nontemporal_load(&F2[jj]);
-                    if (has3) c.d = __builtin_nontemporal_load(&F3[jj]);
-                    if (need_seed) c.sw = __builtin_nontemporal_load(&Sw[jj]);
-                }
-                return c;
-            };
-            S1 n1 = issue1(0), n1b = issue1(64);  // (past the list: nothing is loaded)
-            uint32_t lb_cur;
-            bool alive_cur = eval1(n1, 0, lb_cur);
-            S2 c2 = issue2(0, alive_cur);
-            n1 = n1b;
-            n1b = issue1(128);
-            for (uint32_t p0 = 0; p0 < l_m && !stop; p0 += 64) {
-                // in flight: c2 = the stage-two words / locations of this chunk, n1 / n1b = the stage-one words of the next two
-                const S1 nn1 = issue1(p0 + 192);
-                uint32_t lb_next;
-                const bool alive_next = eval1(n1, p0 + 64, lb_next);
-                const S2 n2 = issue2(p0 + 64, alive_next);
-                uint32_t mm = lb_cur;
-                if (has2) mm += win_count<NEWRULE>(wk[2], c2.c);
-                if (has3) mm += win_count<NEWRULE>(wk[3], c2.d);
-                if (need_seed) mm += win_count16<NEWRULE>(sk, c2.sw);
-                const bool alive = alive_cur && mm <= st.thr;
-#ifdef BASAL_PHASE_TIMING  // long-list chunks; lanes alive after the two near windows; 16-lane groups (128-byte lines of the far words) with such a lane; survivors
-                {
-                    const uint64_t ab = ballot(alive_cur);
-                    phc.n_chunks++; phc.n_alive += (uint32_t)__popcll(ab);
-                    phc.n_bigchunks += ((ab & 0xffffULL) != 0) + ((ab & 0xffff0000ULL) != 0) + ((ab & 0xffff00000000ULL) != 0) + ((ab & 0xffff000000000000ULL) != 0);
-                    phc.n_bigalive += (uint32_t)__popcll(ballot(alive));
-                }
-#endif
-                PH(PH_FILTER);
-                const uint64_t mk = ballot(alive);
-                if (mk) {
-                    if (alive) {
-                        SurvEnt sv;
-                        const uint32_t jj = jj_of(p0 + (uint32_t)lane);
-                        sv.loc = full ? l_off + jj : c2.loc - h;
-                        sv.meta = (uint32_t)(jj >= l_nfwd) | (chain << 1) | (full ? 4u | ((mm & 0xffu) << 3) | (h << 11) : 0u);
-                        L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
+                S1 c;
+#pragma unroll
+                for (int u = 0; u < WD; u++) {
+                    c.a[u] = c.b[u] = 0;
+                    const uint32_t p = p0 + 64u * u + (uint32_t)lane;
+                    if (p < l_m) {
+                        const uint32_t jj = jj_of(p);
+                        if (has0) c.a[u] = __builtin_nontemporal_load(&F0[jj]);
+                        if (has1) c.b[u] = __builtin_nontemporal_load(&F1[jj]);
                     }
-                    nsurv += (uint32_t)__popcll(mk);
-                    wave_sync();
-                    if (nsurv >= 64) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
                 }
-                c2 = n2; lb_cur = lb_next; alive_cur = alive_next; n1 = n1b; n1b = nn1;
+                return c;
+            };
+            S1 n1 = issue1(0);
+            for (uint32_t p0 = 0; p0 < l_m && !stop; p0 += 64u * WD) {
+                uint32_t lb[WD];
+                bool alive1[WD];
+                S2 c2;
+#pragma unroll
+                for (int u = 0; u < WD; u++) {
+                    lb[u] = rc.n_count + win_count<NEWRULE>(wk[0], n1.a[u]) + win_count<NEWRULE>(wk[1], n1.b[u]);
+                    alive1[u] = p0 + 64u * u + (uint32_t)lane < l_m && lb[u] <= st.thr;
+                    c2.loc[u] = c2.sw[u] = 0; c2.c[u] = c2.d[u] = 0;
+                    if (alive1[u]) {
+                        const uint32_t jj = jj_of(p0 + 64u * u + (uint32_t)lane);
+                        if (!full) c2.loc[u] = __builtin_nontemporal_load(&Lc[jj]);  // (a full list's survivors fetch theirs when they are scored: 1 in 7 of these lanes)
+                        if (has2) c2.c[u] = __builtin_nontemporal_load(&F2[jj]);
+                        if (has3) c2.d[u] = __builtin_nontemporal_load(&F3[jj]);
+                        if (need_seed) c2.sw[u] = __builtin_nontemporal_load(&Sw[jj]);
+                    }
+                }
+                n1 = issue1(p0 + 64u * WD);  // (past the list: nothing is loaded)
+#pragma unroll
+                for (int u = 0; u < WD; u++) {
+                    if (stop) break;
+                    uint32_t mm = lb[u];
+                    if (has2) mm += win_count<NEWRULE>(wk[2], c2.c[u]);
+                    if (has3) mm += win_count<NEWRULE>(wk[3], c2.d[u]);
+                    if (need_seed) mm += win_count16<NEWRULE>(sk, c2.sw[u]);
+                    const bool alive = alive1[u] && mm <= st.thr;
+#ifdef BASAL_PHASE_TIMING  // long-list chunks; lanes alive after the near windows; 16-lane groups (128-byte lines of the far words) with such a lane; survivors
+                    {
+                        const uint64_t ab = ballot(alive1[u]);
+                        phc.n_chunks++; phc.n_alive += (uint32_t)__popcll(ab);
+                        phc.n_bigchunks += ((ab & 0xffffULL) != 0) + ((ab & 0xffff0000ULL) != 0) + ((ab & 0xffff00000000ULL) != 0) + ((ab & 0xffff000000000000ULL) != 0);
+                        phc.n_bigalive += (uint32_t)__popcll(ballot(alive));
+                    }
+#endif
+                    PH(PH_FILTER);
+                    const uint64_t mk = ballot(alive);
+                    if (mk) {
+                        if (alive) {
+                            SurvEnt sv;
+                            const uint32_t jj = jj_of(p0 + 64u * u + (uint32_t)lane);
+                            sv.loc = full ? l_off + jj : c2.loc[u] - h;
+                            sv.meta = (uint32_t)(jj >= l_nfwd) | (chain << 1) | (full ? 4u | ((mm & 0xffu) << 3) | (h << 11) : 0u);
+                            L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
+                        }
+                        nsurv += (uint32_t)__popcll(mk);
+                        wave_sync();
+                        if (nsurv >= 64) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
+                    }
+                }
             }
         }
         tcur = rdlane(inc, eh);
