@@ -1892,7 +1892,7 @@ __device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, cons
 #define BASAL_W16G 2
 #endif
 #ifndef BASAL_W4H
-#define BASAL_W4H 6  // HEAVY: the survivor list makes the LDS 24 KB per block (six blocks per CU), and the long-list loop wants its registers
+#define BASAL_W4H 5  // HEAVY: 96 registers for the two-chunk long-list loop (heavy_mode); six waves with 80: 132 against 125 ms per 10 M reads
 #endif
 constexpr int waves_per_simd(int nwt, bool gap, bool heavy = false) {
     // (HEAVY with longer reads: the survivor list and the Bloom filter leave the LDS room for 4 / 3 blocks per CU)
