@@ -210,6 +210,9 @@ __device__ __forceinline__ uint64_t bits64(const uint64_t *pl, int start) {
 #ifndef LONG_WD
 #define LONG_WD 2  // HEAVY kernels: chunks of 64 candidates of a long list per memory round trip (heavy_mode)
 #endif
+#ifndef LONG_WD_NWT
+#define LONG_WD_NWT 8  // ... in the kernels for reads of up to 32 * this many bases
+#endif
 
 struct SurvEnt {  // a gap-eligible or still-alive candidate of the stream
     uint32_t loc;   // alignment start (bounds-checked)
@@ -1244,29 +1247,48 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
         const int eh = hv ? __ffsll((unsigned long long)hv) - 1 : -1;
         const uint32_t tend = eh >= 0 ? rdlane(inc - e_m, eh) : T;
         if (tcur < tend) {  // a stretch of short lists
-            ChunkLoads nxt = issue_chunk<false>(cx, L, inc, end_mask, tcur, tend, lane, nlocs_u, stride, r);
-            for (uint32_t t0 = tcur; t0 < tend && !stop;) {
-                const ChunkLoads cur = nxt;
-                const bool active = t0 + (uint32_t)lane < tend;
-                t0 += 64;
-                if (t0 < tend) nxt = issue_chunk<false>(cx, L, inc, end_mask, t0, tend, lane, nlocs_u, stride, r);
-                bool alive = false;
-                SurvEnt sv = {0, 0};
-                if (active) {
-                    const uint32_t ei = cur.ei, hcs = L.ent[ei].hcs, e_nfwd = L.ent[ei].nfwd;
-                    const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm;  // (as planes: process_read stores them that way for the HEAVY kernels)
-                    const WinP k = {(uint32_t)(e_fr >> 32), (uint32_t)e_fr, (uint32_t)(e_fm >> 32), (uint32_t)e_fm};
-                    alive = rc.n_count + win_count<NEWRULE>(k, cur.f) <= st.thr;
-                    sv.loc = cur.loc_raw - (hcs & 0xffffu);
-                    sv.meta = (uint32_t)(cur.jj >= e_nfwd) | (((hcs >> 16) & 1u) << 1);
+            // (two chunks of 64 stream positions per iteration and memory round trip, as for the long lists below)
+            constexpr int WP = NWT == 4 ? LONG_WD : 1;
+            struct PackedLoads { uint32_t ei, jj, loc_raw; uint64_t f; };
+            auto issue = [&](uint32_t t0, PackedLoads *o) {
+#pragma unroll
+                for (int u = 0; u < WP; u++) {
+                    o[u] = PackedLoads{0, 0, 0, 0};
+                    if (t0 + 64u * u < tend) {
+                        const ChunkLoads c = issue_chunk<false>(cx, L, inc, end_mask, t0 + 64u * u, tend, lane, nlocs_u, stride, r);
+                        o[u] = PackedLoads{c.ei, c.jj, c.loc_raw, c.f};
+                    }
                 }
-                PH(PH_FILTER);
-                const uint64_t mk = ballot(alive);
-                if (mk) {
-                    if (alive) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
-                    nsurv += (uint32_t)__popcll(mk);
-                    wave_sync();
-                    if (nsurv >= 64) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
+            };
+            PackedLoads nxt[WP];
+            issue(tcur, nxt);
+            for (uint32_t t0 = tcur; t0 < tend && !stop; t0 += 64u * WP) {
+                PackedLoads cur[WP];
+#pragma unroll
+                for (int u = 0; u < WP; u++) cur[u] = nxt[u];
+                issue(t0 + 64u * WP, nxt);
+#pragma unroll
+                for (int u = 0; u < WP; u++) {
+                    if (stop) break;
+                    const bool active = t0 + 64u * u + (uint32_t)lane < tend;
+                    bool alive = false;
+                    SurvEnt sv = {0, 0};
+                    if (active) {
+                        const uint32_t ei = cur[u].ei, hcs = L.ent[ei].hcs, e_nfwd = L.ent[ei].nfwd;
+                        const uint64_t e_fr = L.ent[ei].fr, e_fm = L.ent[ei].fm;  // (as planes: process_read stores them that way for the HEAVY kernels)
+                        const WinP k = {(uint32_t)(e_fr >> 32), (uint32_t)e_fr, (uint32_t)(e_fm >> 32), (uint32_t)e_fm};
+                        alive = rc.n_count + win_count<NEWRULE>(k, cur[u].f) <= st.thr;
+                        sv.loc = cur[u].loc_raw - (hcs & 0xffffu);
+                        sv.meta = (uint32_t)(cur[u].jj >= e_nfwd) | (((hcs >> 16) & 1u) << 1);
+                    }
+                    PH(PH_FILTER);
+                    const uint64_t mk = ballot(alive);
+                    if (mk) {
+                        if (alive) L.surv[nsurv + (uint32_t)__popcll(mk & lt)] = sv;
+                        nsurv += (uint32_t)__popcll(mk);
+                        wave_sync();
+                        if (nsurv >= 64) stop = heavy_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
+                    }
                 }
             }
             if (stop) break;
@@ -1331,7 +1353,7 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
             // are requested during the one before; its stage-two words go out as soon as stage one has been looked at, the next iteration's
             // stage-one words right behind them, and the wave waits once for both. (A wave alone on the GPU -- the longest reads at the end of
             // a launch -- is bound by exactly these round trips.)
-            constexpr int WD = NWT == 4 ? LONG_WD : 1;  // (the longer reads' kernels have no registers to spare)
+            constexpr int WD = NWT <= LONG_WD_NWT ? LONG_WD : 1;  // (the longest reads' kernels have no registers to spare)
             struct S1 { uint64_t a[WD], b[WD]; };
             struct S2 { uint32_t loc[WD], sw[WD]; uint64_t c[WD], d[WD]; };
             auto jj_of = [&](uint32_t p) { uint32_t jj = l_jj0 + p; return jj >= l_m ? jj - l_m : jj; };
