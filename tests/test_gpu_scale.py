@@ -38,6 +38,11 @@ CONFIGS = {
     "c5p_realistic": ("T:-", ["-M", "T:-", "-S", "1", "-n", "1", "-g", "3"], 100, 20_000, 0.0, 0.01, dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80),
                       dict(realistic=True, scale=0.05)),
     "c2_realistic_heavy": ("C:T", ["-M", "C:T", "-S", "1"], 100, 200_000, 0.95, 0.01, None, dict(realistic=True, scale=0.4, min_cutoff=32768)),
+    # the HEAVY kernels' other shapes on a genome whose own cut-off selects them: 150-base reads (<8,*,false,HEAVY>: long lists that the four
+    # windows cover -- counted from the stream -- and ones they do not, two chunks per round trip) and T:- (the new-rule window test)
+    "c2_realistic_heavy_150": ("C:T", ["-M", "C:T", "-S", "1"], 150, 100_000, 0.95, 0.01, None, dict(realistic=True, scale=0.4, min_cutoff=32768)),
+    "c5_realistic_heavy": ("T:-", ["-M", "T:-", "-S", "1"], 100, 60_000, 0.0, 0.01, dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80),
+                           dict(realistic=True, scale=0.4, min_cutoff=32768)),
 }
 RELAXED = ("c4_acgt_g2", "c4_acgt_g2_8d", "c4_realistic")  # A:CGT: see the comment in the test
 
@@ -116,7 +121,7 @@ def test_config_matches_oracle_on_sample_and_properties(name):
     # A:CGT seeds only tolerate the conversion to the base coded 11 (A<->T), so reads whose A's became C
     # lose seeds and a share of them cannot be placed -- in the reference too (the oracle sample above agrees)
     realistic = "realistic" in name  # reads from repeats are legitimately multiple there
-    dels = name.startswith("c5") and name.endswith("8d") and "-g" not in flags  # a read with a deleted base cannot be placed without -g
+    dels = name.startswith("c5") and (name.endswith("8d") or name == "c5_realistic_heavy") and "-g" not in flags  # a read with a deleted base cannot be placed without -g
     assert (res["best_level"] != 0xFF).mean() > (0.6 if name in RELAXED or dels else 0.9 if realistic else 0.95)
     uniq_any = (res["best_level"] != 0xFF) & (res["n_hit"].astype(np.uint32) + res["n_chit"] == 1)
     # with -g the reference stores an ungapped and a gapped placement of the same locus as two hits, so many
