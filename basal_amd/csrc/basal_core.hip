@@ -2035,6 +2035,11 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
         }
     }
 #ifdef BASAL_PHASE_TIMING
+    if (lane0(lane)) {  // when this wave found the queue empty (100 MHz clock): latest, earliest (as the complement), sum, count -- the launch's tail
+        const unsigned long long tx = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *ex = (unsigned long long *)(COLDP(unsigned int, guard) + 31) + PH_N + 4 + 32 + PH_N + 8;
+        atomicMax(&ex[0], tx); atomicMax(&ex[1], ~tx); atomicAdd(&ex[2], tx & 0xFFFFFFFFFFull); atomicAdd(&ex[3], 1ull);
+    }
     if (lane0(lane))
     {
         for (int i = 0; i < PH_N; i++) atomicAdd((unsigned long long *)(COLDP(unsigned int, guard) + 31) + i, (unsigned long long)phc.acc[i]);
@@ -2352,9 +2357,17 @@ extern "C" int basal_core_sync_check(basal_core_t *c) {
 #ifdef BASAL_PHASE_TIMING
     {
         static const char *nm[PH_N] = {"queue", "pack", "seeds", "reorder", "mode", "filter", "score", "replay", "final", "chunk", "entry", "bytes", "addhit", "e2", "e3"};
-        unsigned long long ph[PH_N + 4 + 32 + PH_N + 8], tot = 0;
+        unsigned long long ph[PH_N + 4 + 32 + PH_N + 8 + 4], tot = 0;
         HIP_TRY(hipMemcpy(ph, c->d_counter + 32, sizeof ph, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(c->d_counter + 32, 0, sizeof ph));
+        {
+            const unsigned long long *ex = ph + PH_N + 4 + 32 + PH_N + 8;
+            if (ex[3]) {
+                const double last = (double)ex[0], first = (double)~ex[1], mean = (double)ex[2] / (double)ex[3];
+                fprintf(stderr, "[basal wave exits, all launches since the last report] %llu waves; first %.2f ms and mean %.2f ms before the last one (100 MHz clock)\n", ex[3],
+                        (last - first) / 1e5, ((double)(ex[0] & 0xFFFFFFFFFFull) - mean) / 1e5);
+            }
+        }
         fprintf(stderr, "[basal read-time histogram, log2(wave-clocks): count]");
         for (int b = 0; b < 32; b++) if (ph[PH_N + 4 + b]) fprintf(stderr, " %d:%llu", b, ph[PH_N + 4 + b]);
         fprintf(stderr, "\n");
