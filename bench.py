@@ -578,6 +578,12 @@ def main():
         if t:
             roof["traffic"] = t["hbm_bytes_per_read"] * args.batch
             roof["traffic_source"] = t["source"]
+            # the other roof of this integer kernel: vector-instruction issue (a wave64 instruction occupies its 16-lane SIMD for 4 cycles;
+            # 1 024 SIMDs at 2.4 GHz). Reported beside the HBM roofline, from the same counter passes; informational.
+            if t.get("valu_per_read") and roof.get("kernel_ms"):
+                roof["vector_issue"] = {"valu_per_read": t["valu_per_read"],
+                                        "busy_frac": t["valu_per_read"] * 4.0 * args.batch / (1024 * 2.4e9 * roof["kernel_ms"] * 1e-3),
+                                        "note": "SQ_INSTS_VALU per read x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)"}
     # Host-to-host rate: prepared reads in page-locked host buffers -> H2D -> kernel -> D2H of the hit records, three batches in
     # flight on their own streams (basal_pipe_*, BASAL_PIPE_OUT_RESULTS). Reported next to value, never as value.
     if rank == 0 and world == 1 and not os.environ.get("BASAL_BENCH_NO_H2H"):
