@@ -1434,7 +1434,7 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
 
 // ---- one read ----------------------------------------------------------------------------------
 template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
-__device__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
+__device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
                              const uint32_t *pre, int pre_c, int lane PH_PARAM) {
     using LDS = WaveLds<NWT, GAP, HEAVY>;
     static_assert(!(GAP && HEAVY), "the HEAVY path is the non-GAP kernels'");
@@ -1966,8 +1966,8 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
     // (the pipeline's extras -- a list of read numbers, its length in device memory -- are re-read from the kernel arguments where they
     // are used, once per chunk of reads: held in registers across the work loop they cost the standard launch spills)
 #define LISTED (COLD(order) != nullptr)
-    if (COLD(n_ptr) && *COLDP(const uint32_t, n_ptr) == 0) return;  // (a read-length class without reads: no queue traffic)
-    for (uint32_t iter = 0;; iter++) {
+    const bool no_reads = COLD(n_ptr) && *COLDP(const uint32_t, n_ptr) == 0;  // (a read-length class without reads: no queue traffic)
+    for (uint32_t iter = 0; !no_reads; iter++) {
         uint32_t n_items = cx.n;
         if (COLD(n_ptr)) { n_items = *COLDP(const uint32_t, n_ptr); n_items = n_items < cx.n ? n_items : cx.n; }  // cx.n: the capacity of the list
         // the whole wave must arrive here together (see lane0()); a partial wave is an internal error
@@ -2033,6 +2033,12 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
             if (!LISTED) ((uint32_t *)(COLDP(basal_result, results) + base))[lane] = ((const uint32_t *)L.res)[lane];
             else ((uint32_t *)(COLDP(basal_result, results) + L.rno[lane >> 3]))[lane & 7] = ((const uint32_t *)L.res)[lane];  // still one store instruction per chunk
         }
+    }
+    // The last wave out leaves the queue head at zero for the next launch on this counter block (word 26 counts the waves that are through): a
+    // memset in front of every launch queued behind the copy of the previous launch's results when both went through the same engine.
+    if (lane0(lane)) {
+        unsigned int *wc = cx.work_counter;
+        if (atomicAdd(&wc[26], 1u) == gridDim.x * 4u - 1u) { atomicExch(&wc[26], 0u); atomicExch(&wc[0], 0u); }
     }
 #ifdef BASAL_PHASE_TIMING
     if (lane0(lane)) {  // when this wave found the queue empty (100 MHz clock): latest, earliest (as the complement), sum, count -- the launch's tail
@@ -2303,7 +2309,10 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         if (cx.heavy_m < 1) cx.heavy_m = 1;
     }
     kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv) : nwt == 8 ? pick_kernel<8>(nr, gp, hv) : pick_kernel<16>(nr, gp, hv);
-    HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));  // queue head only; the ledger accumulates until it is read
+    {   // the queue head is zero: the counter block was allocated so, and the last wave of a launch leaves it so (BASAL_HEAD_MEMSET=1: a memset as well)
+        static const bool ms = getenv("BASAL_HEAD_MEMSET") && atoi(getenv("BASAL_HEAD_MEMSET")) != 0;
+        if (ms) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));
+    }
     cx.guard = counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
     const char *env = getenv("BASAL_BLOCKS_PER_CU");
