@@ -2341,6 +2341,17 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     return BASAL_OK;
 }
 
+// A few words set to a value by a kernel on the caller's stream. (hipMemsetAsync in front of a launch queued behind a device-to-host copy that
+// another stream had in flight -- 4-7 ms per 10 M-read step of bench.py -- where a kernel does not.)
+namespace { __global__ void fill_words(uint32_t *p, uint32_t n, uint32_t v) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; } }
+int basal_fill_async(void *p, size_t bytes, uint32_t value, hipStream_t s) {
+    const uint32_t n = (uint32_t)(bytes / 4);
+    if (!n) return BASAL_OK;
+    hipLaunchKernelGGL(fill_words, dim3((n + 255) / 256), dim3(256), 0, s, (uint32_t *)p, n, value);
+    HIP_TRY(hipGetLastError());
+    return BASAL_OK;
+}
+
 int basal_launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
                        uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, hipStream_t s,
                        const basal_align_extra *ex) {

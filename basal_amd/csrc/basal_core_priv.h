@@ -80,6 +80,7 @@ int basal_launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev, 
 int basal_launch_align_carry(basal_core *c, const void *d_bases, uint64_t nbases_dev, const void *d_reads, uint32_t n, const void *d_stales, uint32_t nstale,
                              uint32_t max_len, int stream_mode, void *d_results, void *d_stream, uint64_t stream_cap, void *d_stream_used, const uint8_t carry[2][2],
                              hipStream_t s, const basal_align_extra *ex);
+int basal_fill_async(void *p, size_t bytes, uint32_t value, hipStream_t s);  // bytes: a multiple of 4; a kernel, not a memset (see the definition)
 int basal_pe_enqueue(basal_core *c, const void *d_reads, const void *d_results, const void *d_stream, void *d_work, uint32_t npairs, void *d_pairs, void *d_recs,
                      uint64_t recs_cap, void *d_recs_used, void *d_stats, hipStream_t s);
 int basal_validate_batch(const basal_params &P, const basal_read *reads, uint32_t n, uint64_t nbases, const basal_stale *stales, uint32_t nstale, const char *who,

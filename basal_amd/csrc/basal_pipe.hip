@@ -342,8 +342,7 @@ static int queue_format(basal_pipe *p, Slot &s) {
     SlotDev &d = s.d;
     if (!(p->o.flags & BASAL_PIPE_PAIRS)) return prep_enqueue_format(c, p->k, d, v.sh, p->o.max_reads, v.st_comp);
     const uint32_t npairs = s.n_host / 2;
-    HIP_TRYQ(hipMemsetAsync(&d.cnt->pe[0], 0, sizeof d.cnt->pe, v.st_comp));
-    HIP_TRYQ(hipMemsetAsync(&d.cnt->pe_recs_used, 0, sizeof d.cnt->pe_recs_used, v.st_comp));
+    if (basal_fill_async(&d.cnt->pe[0], sizeof d.cnt->pe, 0, v.st_comp) || basal_fill_async(&d.cnt->pe_recs_used, sizeof d.cnt->pe_recs_used, 0, v.st_comp)) return BASAL_EDEVICE;
     int rc = basal_pe_enqueue(c, d.desc, d.results, d.stream, d.pe_work, npairs, d.pe_pairs, d.pe_recs, d.pe_recs_cap, &d.cnt->pe_recs_used, d.cnt->pe, v.st_comp);
     if (rc) return rc;
     return prep_enqueue_format_pe(c, p->k, d, v.sh, npairs, p->o.max_reads, v.st_comp);
@@ -407,7 +406,7 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     // kernels (this stream also keeps the batches' carry states in order)
     TRYS(hipStreamWaitEvent(v.st_comp, s.ev[EV_H2D], 0));
     TRYS(hipEventRecord(s.ev[EV_COMP0], v.st_comp));
-    TRYS(hipMemsetAsync(d.cnt, 0, sizeof(BatchCounters), v.st_comp));
+    if (basal_fill_async(d.cnt, sizeof(BatchCounters), 0, v.st_comp)) return BASAL_EDEVICE;
     if (mode != MODE_PREPARED && src_dev >= 0 && src_dev != s.dev) {
         // the state this batch starts from was written on another GPU, by the prep kernels of the batch before: fetch it behind them
         PipeDev &w = p->devs[(size_t)src_dev];
@@ -429,7 +428,7 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     TRYS(hipStreamWaitEvent(v.st_cnt, s.ev[EV_FORMAT], 0));
     TRYS(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, v.st_cnt));
     TRYS(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, v.st_cnt));
-    TRYS(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), v.st_cnt));
+    if (basal_fill_async(d.counter + 1, 24 * sizeof(unsigned int), 0, v.st_cnt)) return BASAL_EDEVICE;
     TRYS(hipEventRecord(s.ev[EV_COUNTERS], v.st_cnt));
     if (mode == MODE_PREPARED) {  // the size of the output is known: queue its copy right behind the kernel
         TRYS(hipStreamWaitEvent(v.st_out, s.ev[EV_FORMAT], 0));
