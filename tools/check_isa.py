@@ -45,6 +45,13 @@ def main():
         m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\d+)", l)
         if m and name:
             print("%-60s %-28s %s" % (name[-60:], m.group(1), m.group(2)))
+    # a device function that was NOT inlined into its kernel (it then takes LDS and global pointers as generic ones: flat loads, a stack of
+    # several hundred bytes per lane) -- every function of this file is meant to end up inside an align_kernel instantiation or a small kernel
+    for l in lines:
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+(process_read|heavy_mode|heavy_flush|bulk_add|prep_read|reorder_seed|add_hit|gap_align)\w*):", l)
+        if m:
+            print("not inlined: %s" % m.group(1)[:100])
+            bad += 1
     if re.search(r"\bflat_(load|store)", "\n".join(lines)):
         print("flat_* memory instructions present (LDS/global address space not resolved)")
         bad += 1
