@@ -207,6 +207,9 @@ __device__ __forceinline__ uint64_t bits64(const uint64_t *pl, int start) {
 #ifndef WORK_CHUNK
 #define WORK_CHUNK 8  // reads a wave takes from the queue per atomic
 #endif
+#ifndef BLOOM_WORDS
+#define BLOOM_WORDS 256  // 8 192 bits: 123.0 -> 119.0 ms per 10 M reads against 4 096 (fewer look-ups of the memory log for reads with a thousand hits); 16 384 would cost the fifth block per CU
+#endif
 #ifndef LONG_WD
 #define LONG_WD 2  // HEAVY kernels: chunks of 64 candidates of a long list per memory round trip (heavy_mode)
 #endif
@@ -238,7 +241,7 @@ struct HeavyLds {};
 template <>
 struct HeavyLds<true> {
     SurvEnt surv[128];    // meta = reference strand | read chain << 1; counted from the stream already: | 4 | the count << 3 | the seed's read offset << 11, and loc = the index entry
-    uint32_t bloom[128];  // a 4096-bit Bloom filter over the keys of ALL stored hits of the read (bulk_add)
+    uint32_t bloom[BLOOM_WORDS];  // a Bloom filter (4096 bits by default) over the keys of ALL stored hits of the read (bulk_add)
     uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
 
@@ -1061,7 +1064,10 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
     if (strand) l = rcoff - rc.len - l;
     pend &= ballot((int)l >= 0 && l + rc.len <= csize);  // AddHit's two bounds (align.h:330-331)
     const uint64_t key = hit_key(chr >> 1, l, false);
-    const uint32_t bh = bloom_hash(key), b1 = bh & 4095u, b2 = (bh >> 12) & 4095u, bk = bh >> 27;
+    const uint32_t bh = bloom_hash(key), b1 = bh & (BLOOM_WORDS * 32u - 1u), b2 = (bh >> 13) & (BLOOM_WORDS * 32u - 1u), bk = bh >> 27;
+#ifdef BLOOM_K3
+    const uint32_t b3 = ((bh * 0x9E3779B1u) >> 18) & (BLOOM_WORDS * 32u - 1u);
+#endif
     HitWords u;
     u.h.loc = l; u.h.chr = chr; u.h.gap_size = 0; u.h.strand = (uint8_t)(((strand << 1) | chain) & 3);
     u.h.gap_pos = (uint16_t)(strand ? rc.len & 0x1FFu : 0u);  // int2hit mirrors gap_pos on the reverse strand even without a gap (align.cpp:341)
@@ -1093,7 +1099,11 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
         // Duplicates of stored hits: a key the Bloom filter (all stored keys of the read) has not seen is new; the few it may have seen
         // are looked up one by one -- the 64 records in registers with one compare + ballot, the rest of the log by scanning it.
         {
+#ifdef BLOOM_K3
+            const bool maybe = st.nlog && ((L.bloom[b1 >> 5] >> (b1 & 31)) & (L.bloom[b2 >> 5] >> (b2 & 31)) & (L.bloom[b3 >> 5] >> (b3 & 31)) & 1u);
+#else
             const bool maybe = st.nlog && ((L.bloom[b1 >> 5] >> (b1 & 31)) & (L.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
+#endif
             uint64_t chk = ballot(maybe) & acc & ~dup;
             if (chk) {
                 const uint64_t regk = hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0);
@@ -1145,6 +1155,9 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
             if (mine) {
                 atomicOr(&L.bloom[b1 >> 5], 1u << (b1 & 31));
                 atomicOr(&L.bloom[b2 >> 5], 1u << (b2 & 31));
+#ifdef BLOOM_K3
+                atomicOr(&L.bloom[b3 >> 5], 1u << (b3 & 31));
+#endif
                 atomicAdd(&L.nhit[chain][mm & 15], 1u);
             }
             st.nlog = n0 + cnt < spw ? n0 + cnt : spw;
@@ -1485,7 +1498,10 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
         wave_sync();
     }
     if (lane < 32) L.nhit[lane >> 4][lane & 15] = 0;
-    if constexpr (HEAVY) { L.bloom[lane] = 0; L.bloom[lane + 64] = 0; }
+    if constexpr (HEAVY) {
+#pragma unroll
+        for (int i = 0; i < BLOOM_WORDS / 64; i++) L.bloom[lane + 64 * i] = 0;
+    }
     wave_sync();
     reorder_seed(cx, L, rc, lane, so0, so1);
     res.start_off[0] = (uint8_t)so0;
