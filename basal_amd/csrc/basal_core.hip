@@ -236,17 +236,17 @@ struct GapLds<NWT, true> {
 };
 
 // what only the HEAVY kernels keep per wave: the candidates that passed the stream's window tests, in visitation order, scored 64 at a time
-template <bool HEAVY>
+template <bool HEAVY, int NWT>
 struct HeavyLds {};
-template <>
-struct HeavyLds<true> {
+template <int NWT>
+struct HeavyLds<true, NWT> {
     SurvEnt surv[128];    // meta = reference strand | read chain << 1; counted from the stream already: | 4 | the count << 3 | the seed's read offset << 11, and loc = the index entry
-    uint32_t bloom[BLOOM_WORDS];  // a Bloom filter (4096 bits by default) over the keys of ALL stored hits of the read (bulk_add)
+    uint32_t bloom[NWT <= 8 ? BLOOM_WORDS : 128];  // a Bloom filter over the keys of ALL stored hits of the read (bulk_add); the 480-base kernels keep 4 096 bits, their LDS holds three blocks per CU only so
     uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
 
 template <int NWT, bool GAP, bool HEAVY = false>
-struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY> {
+struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT> {
     static constexpr int NW = NWT;
     static constexpr int MAXPOS = NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
@@ -1064,9 +1064,10 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
     if (strand) l = rcoff - rc.len - l;
     pend &= ballot((int)l >= 0 && l + rc.len <= csize);  // AddHit's two bounds (align.h:330-331)
     const uint64_t key = hit_key(chr >> 1, l, false);
-    const uint32_t bh = bloom_hash(key), b1 = bh & (BLOOM_WORDS * 32u - 1u), b2 = (bh >> 13) & (BLOOM_WORDS * 32u - 1u), bk = bh >> 27;
+    constexpr uint32_t kBloomBits = (uint32_t)(sizeof(L.bloom) * 8);
+    const uint32_t bh = bloom_hash(key), b1 = bh & (kBloomBits - 1u), b2 = (bh >> 13) & (kBloomBits - 1u), bk = bh >> 27;
 #ifdef BLOOM_K3
-    const uint32_t b3 = ((bh * 0x9E3779B1u) >> 18) & (BLOOM_WORDS * 32u - 1u);
+    const uint32_t b3 = ((bh * 0x9E3779B1u) >> 18) & (kBloomBits - 1u);
 #endif
     HitWords u;
     u.h.loc = l; u.h.chr = chr; u.h.gap_size = 0; u.h.strand = (uint8_t)(((strand << 1) | chain) & 3);
@@ -1500,7 +1501,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
     if (lane < 32) L.nhit[lane >> 4][lane & 15] = 0;
     if constexpr (HEAVY) {
 #pragma unroll
-        for (int i = 0; i < BLOOM_WORDS / 64; i++) L.bloom[lane + 64 * i] = 0;
+        for (int i = 0; i < (int)(sizeof(L.bloom) / 256); i++) L.bloom[lane + 64 * i] = 0;
     }
     wave_sync();
     reorder_seed(cx, L, rc, lane, so0, so1);
