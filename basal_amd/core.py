@@ -135,6 +135,7 @@ SYMBOLS = [
     ("basal_multi_destroy", None, [_vp]),
     ("basal_multi_ndev", _i, [_vp]),
     ("basal_multi_core", _vp, [_vp, _i]),
+    ("basal_multi_last_h2d_bytes", _u64, [_vp, _i]),
     ("basal_multi_upload", _i, [_vp, _vp, _i, _P(_u32)]),
     ("basal_multi_align_batch", _i, [_vp, _vp, _u64, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _P(_u64), _vp]),
     ("basal_pipe_set_read_range", _i, [_vp, _u32, _u32]),

@@ -23,6 +23,7 @@
 // issue and per-read latency all bound it about equally.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -90,6 +91,10 @@ struct DevCtx {
     const uint32_t *order;
     const uint32_t *n_ptr;
     uint32_t ghost_base;
+    // GAP cores: both strands once more as bit planes, one 16-byte block per 64 bases (.x = high bits of the base codes, .y = low bits, bit i =
+    // base i of the block): a gap-search candidate's bitmaps at every shift are funnel shifts + three bit-selects per 64 bases (gap_flush)
+    const ulonglong2 *xpl[2];
+    uint32_t lds_poison;  // check build: 0x100 | byte = fill the LDS with that byte at kernel start (BASAL_POISON)
 };
 
 enum { G_KMER = 0, G_LOCS = 1, G_XREF = 2, G_BASES = 3, G_LDSPOS = 4, G_STALE = 5, G_KMER2 = 6, G_WATCHDOG = 7 };
@@ -232,7 +237,13 @@ struct GapLds<NWT, true> {
     // a zero word on either side of the NWT/2 data words, so that a window at any position is two loads and a funnel shift, no branches
     uint64_t mmp[2][4][NWT / 2 + 2];
     uint64_t valp[2][NWT / 2 + 2];
-    SurvEnt surv[128];            // the candidates the flank tests could not rule out, in visitation order
+};
+// the candidates the stream's tests could not rule out, in visitation order (GAP and HEAVY kernels), scored 64 at a time
+template <bool ON>
+struct SurvLds {};
+template <>
+struct SurvLds<true> {
+    alignas(16) SurvEnt surv[128];  // GAP: see SurvEnt; HEAVY non-GAP: meta = reference strand | read chain << 1; counted from the stream already: | 4 | the count << 3 | the seed's read offset << 11, and loc = the index entry
 };
 
 // what only the HEAVY kernels keep per wave: the candidates that passed the stream's window tests, in visitation order, scored 64 at a time
@@ -240,13 +251,12 @@ template <bool HEAVY, int NWT>
 struct HeavyLds {};
 template <int NWT>
 struct HeavyLds<true, NWT> {
-    SurvEnt surv[128];    // meta = reference strand | read chain << 1; counted from the stream already: | 4 | the count << 3 | the seed's read offset << 11, and loc = the index entry
     uint32_t bloom[NWT <= 8 ? BLOOM_WORDS : 128];  // a Bloom filter over the keys of ALL stored hits of the read (bulk_add); the 480-base kernels keep 4 096 bits, their LDS holds three blocks per CU only so
     uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
 
 template <int NWT, bool GAP, bool HEAVY = false>
-struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT> {
+struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY> {
     static constexpr int NW = NWT;
     static constexpr int MAXPOS = NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
@@ -1171,6 +1181,419 @@ __device__ bool bulk_add(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log,
     }
 }
 
+// ---- HEAVY GAP kernels: the survivors' stage on bit planes -------------------------------------------------------------------------------
+// Where long lists are the rule (an index with a high over-represented-k-mer cut-off: a repeat-rich genome) the GAP kernels meet hundreds of
+// near-copies per read that no flank bound can drop; what they cost is the gap search itself and the one-by-one AddHit. These kernels
+// (align_kernel<*, *, true, true>) keep the stream filter of the GAP kernels and replace the stage behind it (gap_flush):
+//   * the survivor's reference bases come from a second copy of the reference kept as BIT PLANES (DevCtx::xpl), so its mismatch bitmap at the
+//     candidate's start and at every shifted start is a funnel shift and three bit-selects per 64 bases, one bit per read base, LSB first;
+//   * GapAlign (align.cpp:348-410) runs on those bitmaps (gap_search): the same decisions as gap_align above, at a third of the instructions;
+//   * the ungapped hit and the gapped hit of up to 64 candidates are booked at once (bulk_add2), in the order the reference books them --
+//     candidate by candidate, the ungapped hit first (align.cpp:308-312).
+
+__device__ __forceinline__ uint64_t low_mask64(int n) { return n <= 0 ? 0ULL : n >= 64 ? ~0ULL : (1ULL << n) - 1; }
+// set bits of an NW-word bitmap (bit p of word p / 64 = read position p) at positions < n / >= n
+template <int NW>
+__device__ __forceinline__ uint32_t popc_below(const uint64_t *D, int n) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) c += popc64(D[w] & low_mask64(n - 64 * w));
+    return c;
+}
+template <int NW>
+__device__ __forceinline__ uint32_t popc_from(const uint64_t *D, int n) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) c += popc64(D[w] & ~low_mask64(n - 64 * w));
+    return c;
+}
+// bits [sh, sh + 64) of the 128-bit value hi:lo, sh < 64
+__device__ __forceinline__ uint64_t funnel64(uint64_t lo, uint64_t hi, uint32_t sh) { return (lo >> sh) | ((hi << 1) << (63 - sh)); }
+
+// The read's mismatch bitmap against the reference shifted by `sh` bits: Rh / Rl = the reference's bit planes from base (candidate start - g) on,
+// M = L.mmp[chain] ("this read base mismatches letter X", one zero word in front; zero past the read): the word loop of MismatchPattern0/1
+// (align.h:140-165, 179-193) for both rules -- the comparison is per base, so the masks are exact for every -M rule.
+template <int NW>
+__device__ __forceinline__ void plane_bitmap(const uint64_t Rh[NW + 1], const uint64_t Rl[NW + 1], uint32_t sh, const uint64_t (*M)[NW + 2], uint64_t D[NW]) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint64_t m[4] = {M[0][w + 1], M[1][w + 1], M[2][w + 1], M[3][w + 1]};
+        D[w] = plane_mismatch(funnel64(Rh[w], Rh[w + 1], sh), funnel64(Rl[w], Rl[w + 1], sh), m);
+    }
+}
+
+// position of the k-th set bit of x counted from the top (k >= 1; x holds at least k bits): a binary search on popcounts, no loop
+__device__ __forceinline__ int select_from_top64(uint64_t x, uint32_t k) {
+    uint32_t v = (uint32_t)(x >> 32), c = (uint32_t)__popc(v);
+    int base = 32;
+    if (k > c) { v = (uint32_t)x; base = 0; k -= c; }
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1) {  // the upper half of the h*2 bits still in play holds c bits: the k-th is there, or it is the (k - c)-th of the lower half
+        const uint32_t up = v >> h;
+        c = (uint32_t)__popc(up);
+        const bool in_up = k <= c;
+        v = in_up ? up : v & ((1u << h) - 1u);
+        base += in_up ? h : 0;
+        k -= in_up ? 0u : c;
+    }
+    return base;
+}
+// the same over an NW-word bitmap; -1 if it holds fewer than k bits
+template <int NW>
+__device__ __forceinline__ int kth_from_top(const uint64_t *D, uint32_t k) {
+    uint64_t x = 0;
+    int wbase = -1;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; w--) {
+        const uint32_t c = popc64(D[w]);
+        const bool here = wbase < 0 && k <= c;
+        if (here) { x = D[w]; wbase = 64 * w; }
+        if (wbase < 0) k -= c;
+    }
+    return wbase < 0 ? -1 : wbase + select_from_top64(x, k);
+}
+
+// GapAlign (align.cpp:348-410) for one candidate on one-bit-per-base bitmaps: D0 = the ungapped bitmap (no N mask, as MismatchPattern0), the
+// shifted bitmaps are cut from the planes Rh / Rl (bit k = reference base start - g + k). The reference walks, per shift, the left-side mismatches
+// mmi1[i] in order and, for each, the right-side mismatches mmi2[j] (align.cpp:383-404); a left-side mismatch at gp can only complete a hit if
+// fewer than thr - t right-side mismatches lie at or behind pcut = min(gp - shift1, len - gap_edge) -- so with p* = one past the (thr - t)-th
+// right-side mismatch from the read's end (one popcount search, no loop) only the left-side mismatches in [p* + shift1, len - t - 1) are looked
+// at, usually none: the same first (tt, i, j) as the reference's loops (and as gap_align above), without walking the ones that cannot win.
+template <int NW>
+__device__ bool gap_search(const DevCtx &cx, const uint64_t Rh[NW + 1], const uint64_t Rl[NW + 1], const uint64_t (*M)[NW + 2], const uint64_t D0[NW], const ReadCtx &rc,
+                           uint32_t thr, uint32_t seed_pos, uint32_t &gap_snp, uint32_t &gap_pos_out, int &shift_out) {
+    if (thr < 2) return false;
+    const int len = (int)rc.len, ge = (int)cx.gap_edge;
+    // MismatchPattern0's return value against seed_pos + seed_size (align.cpp:365): thr-1 mismatches before the end of the seed end the search
+    if (popc_below<NW>(D0, (int)(seed_pos + cx.K)) >= thr - 1) return false;
+    for (uint32_t tt = 1; tt <= cx.gap * 2; tt++) {
+        const uint32_t t = (tt + 1) / 2;
+        const int shift = (tt & 1) ? -(int)t : (int)t, shift1 = shift < 0 ? shift : 0;
+        if (thr < 1 + t) break;
+        uint64_t D1[NW];
+        plane_bitmap<NW>(Rh, Rl, (uint32_t)((int)cx.gap + shift), M, D1);
+        {   // a base that mismatches at both starts costs one mismatch wherever the gap falls (the t inserted bases excepted)
+            uint32_t both = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) both += popc64(D0[w] & D1[w]);
+            if (both >= thr - t + (shift < 0 ? t : 0)) continue;
+        }
+        const int pstar = kth_from_top<NW>(D1, thr - t) + 1;  // popc(D1 at positions >= p) < thr - t  <=>  p >= pstar
+        if (pstar > len - ge) continue;
+        const int rl = len - (int)t - 1;
+        int lo = pstar + shift1;
+        if (lo < ge) lo = ge;
+        uint64_t cand[NW], any = 0;  // the left-side mismatches worth a look: gap_edge <= gp < rl (align.cpp:385) and pcut >= p*
+#pragma unroll
+        for (int w = 0; w < NW; w++) { cand[w] = D0[w] & ~low_mask64(lo - 64 * w) & low_mask64(rl - 64 * w); any |= cand[w]; }
+        if (!any) continue;
+        uint32_t i = popc_below<NW>(D0, lo);  // index of the current left-side mismatch (mmi1[i])
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            uint64_t bits = cand[w];
+            while (bits && i < thr - t) {
+                int gp = w * 64 + __ffsll((unsigned long long)bits) - 1;
+                bits &= bits - 1;
+                int X = len + shift1 - gp;
+                if (X < ge) X = ge;
+                const int pcut = len - X;  // right-side mismatches at positions >= pcut are at distance < X from the read's end
+                uint32_t jstar = 0;
+                int plast = -1;            // the highest mismatch position < pcut
+#pragma unroll
+                for (int v = 0; v < NW; v++) {
+                    const uint64_t pre = low_mask64(pcut - 64 * v);
+                    jstar += popc64(D1[v] & ~pre);
+                    const uint64_t lw = D1[v] & pre;
+                    if (lw) plast = v * 64 + 63 - __clzll((long long)lw);
+                }
+                if (plast >= 0 && jstar < thr - t - i) {
+                    const int m2 = len - 1 - plast;
+                    if (m2 < rl) {  // m2 >= X >= gap_edge by construction
+                        gap_snp = i + jstar + t;
+                        const int clip = gp + ge - len - shift1;
+                        if (clip > 0) gp -= clip;
+                        gap_pos_out = (uint32_t)gp;
+                        shift_out = shift;
+                        return true;
+                    }
+                }
+                i++;
+            }
+        }
+    }
+    return false;
+}
+
+// Which lanes of `acc` hold a key that an EARLIER lane of `acc` holds too. In rounds: every open lane aims at the bucket of its key's hash, the
+// lowest lane of a bucket is the first of its key; the others compare their key with that lane's -- equal: a duplicate; not equal (two keys in
+// one bucket): open for the next round. Equal keys share a bucket, so nothing is missed. (bulk_add's rounds, as a function.)
+template <class LDS>
+__device__ uint64_t dups_among(LDS &L, uint64_t acc, uint64_t key, uint32_t bk, int lane) {
+    uint64_t dup = 0;
+    if (!(acc & (acc - 1))) return 0;
+    for (uint64_t open = acc; open;) {
+        if (lane < 32) L.bucket[lane] = 0xFFFFFFFFu;
+        wave_sync();
+        const bool in = (open >> lane) & 1;
+        if (in) atomicMin(&L.bucket[bk], (uint32_t)lane);
+        wave_sync();
+        const uint32_t w = in ? L.bucket[bk] & 63u : (uint32_t)lane;
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)(uint32_t)key), khi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)(uint32_t)(key >> 32));
+        const bool same = klo == (uint32_t)key && khi == (uint32_t)(key >> 32);
+        const uint64_t first_m = ballot(w == (uint32_t)lane) & open, dup_m = ballot(w != (uint32_t)lane && same) & open;
+        dup |= dup_m;
+        open &= ~(first_m | dup_m);
+    }
+    return dup;
+}
+// Which lanes of `cand` hold a key that is already stored: the Bloom filter over all stored keys of the read says "certainly not" for most; the
+// rest are looked up one by one (the 64 records in registers by compare + ballot, the memory part of the log by scanning it).
+template <class LDS>
+__device__ uint64_t dups_stored(LDS &L, const HitState &st, const basal_hit *log, uint64_t cand, uint64_t key, uint32_t b1, uint32_t b2, int lane) {
+    const bool maybe = st.nlog && ((L.bloom[b1 >> 5] >> (b1 & 31)) & (L.bloom[b2 >> 5] >> (b2 & 31)) & 1u);
+    uint64_t chk = ballot(maybe) & cand, dup = 0;
+    if (chk) {
+        const uint64_t regk = hit_key(st.d1 >> 1, st.d0, (st.d2 & 0xffu) != 0);
+        const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
+        for (; chk; chk &= chk - 1) {
+            const int la = __ffsll((unsigned long long)chk) - 1;
+            const uint64_t kb = rdlane64(key, la);
+            bool known = (ballot(regk == kb) & in_regs) != 0;
+            if (!known && st.nlog > 64) known = log_has_key(st, log, kb, lane);
+            if (known) dup |= 1ULL << la;
+        }
+    }
+    return dup;
+}
+
+// int2hit + AddHit (align.cpp:319-346, align.h:329-347) for up to 64 candidates AT ONCE, each with an ungapped hit (level mmU) and / or a gapped
+// one (gfound: level gsnp, shift gshift, position gpos), lane order = visitation order, within a lane the ungapped hit first (SnpAlign books it
+// before it calls GapAlign, align.cpp:308-312). bulk_add's scheme over 128 slots (2 * lane + kind): every lane places both hits and forms both
+// keys (ungapped and gapped hits are de-duplicated apart, align.h:332-337, so the two kinds never meet); duplicates among the lanes and of
+// stored hits per kind; per level present, the slot at which the running total reaches the -w cap; everything up to the first such slot is
+// appended in slot order, the threshold drops to that level - 1 and the call returns: the slots after it must be looked at again under the new
+// threshold, and the gap search -- whose result depends on the threshold -- run again for them (the caller does that).
+// pendU / pendG: the lanes whose ungapped / gapped slot is still open (in and out). Returns BA_DONE (nothing open any more), BA_STOP (a level-0
+// cap: SnpAlign must stop) or BA_RETHR (st.thr was lowered; pendU / pendG hold what is left).
+enum { BA_DONE = 0, BA_STOP = 1, BA_RETHR = 2 };
+template <class LDS>
+__device__ int bulk_add2(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint64_t &pendU, uint64_t &pendG, uint32_t loc, uint32_t strand,
+                         uint32_t chain, uint32_t mmU, bool gfound, uint32_t gsnp, uint32_t gpos, int gshift, uint32_t mode, uint32_t r, int lane) {
+    uint64_t accU = pendU & ballot(mmU <= st.thr), accG = pendG & ballot(gfound);
+    if (!(accU | accG)) { pendU = pendG = 0; return BA_DONE; }
+    const uint64_t lt = (1ULL << lane) - 1;
+    // int2hit's search of ref_anchor (align.cpp:325-329), as in bulk_add: s_anchor holds the whole table (<= 64 contigs) or 64 pivots of it
+    const uint32_t nc = COLD(ncontig);
+    const uint32_t pstride = (nc + 63) / 64;
+    uint32_t left;
+    {
+        uint32_t lo = 0, hi = (nc + pstride - 1) / pstride;
+#pragma unroll 1
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool go = hi - lo > 1, ge = s_anchor[mid & 63] <= loc;
+            lo = go && ge ? mid : lo;
+            hi = go && !ge ? mid : hi;
+        }
+        left = lo;
+        if (nc > 64) {
+            lo = left * pstride;
+            hi = lo + pstride < nc ? lo + pstride : nc;
+            while (ballot(hi - lo > 1)) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const bool go = hi - lo > 1, ge = COLDP(const uint32_t, ref_anchor)[mid < nc ? mid : 0] <= loc;
+                lo = go && ge ? mid : lo;
+                hi = go && !ge ? mid : hi;
+            }
+            left = lo;
+        }
+    }
+    const uint32_t chr = (left * 2 + strand) & 0x3FFFF;
+    const uint32_t wc = chr >> 1;  // the 18-bit wrap of gHit.chr (see add_hit)
+    uint32_t anchor, csize, rcoff;
+    if (nc <= 64) { anchor = s_anchor[left & 63]; csize = s_csize[left & 63]; rcoff = s_rcoff[left & 63]; asm volatile("" : "+v"(rcoff), "+v"(csize), "+v"(anchor)); }
+    else {
+        const uint32_t wci = wc < nc ? wc : 0;
+        anchor = COLDP(const uint32_t, ref_anchor)[left]; csize = COLDP(const uint32_t, contig_size)[wci]; rcoff = COLDP(const uint32_t, rc_offset)[wci];
+        asm volatile("" : "+v"(rcoff), "+v"(csize), "+v"(anchor));
+    }
+    // the two hits as int2hit leaves them (align.cpp:334-345)
+    uint32_t lU = loc - anchor, lG = lU, gpU = 0, gpG = gpos & 0x1FFu;
+    if (strand) {
+        lU = rcoff - rc.len - lU;
+        gpU = rc.len & 0x1FFu;
+        gpG = (uint32_t)((int)rc.len + (gshift < 0 ? gshift : 0) - (int)gpG) & 0x1FFu;
+        lG = lU - (uint32_t)gshift;
+    }
+    accU &= ballot((int)lU >= 0 && lU + rc.len <= csize);  // AddHit's two bounds (align.h:330-331)
+    accG &= ballot((int)lG >= 0 && lG + rc.len <= csize);
+    const uint64_t keyU = hit_key(chr >> 1, lU, false), keyG = hit_key(chr >> 1, lG, true);
+    constexpr uint32_t kBloomBits = (uint32_t)(sizeof(L.bloom) * 8);
+    const uint32_t bhU = bloom_hash(keyU), bhG = bloom_hash(keyG);
+    const uint32_t u1 = bhU & (kBloomBits - 1u), u2 = (bhU >> 13) & (kBloomBits - 1u), g1 = bhG & (kBloomBits - 1u), g2 = (bhG >> 13) & (kBloomBits - 1u);
+    HitWords hU, hG;
+    hU.h.loc = lU; hU.h.chr = chr; hU.h.gap_size = 0; hU.h.strand = (uint8_t)(((strand << 1) | chain) & 3); hU.h.gap_pos = (uint16_t)gpU;
+    hU.h.level = (uint8_t)mmU; hU.h.chain = (uint8_t)chain; hU.h.mode = (uint8_t)mode; hU.h.pad = 0;
+    hG.h.loc = lG; hG.h.chr = chr; hG.h.gap_size = (int8_t)gshift; hG.h.strand = hU.h.strand; hG.h.gap_pos = (uint16_t)gpG;
+    hG.h.level = (uint8_t)gsnp; hG.h.chain = (uint8_t)chain; hG.h.mode = (uint8_t)mode; hG.h.pad = 0;
+    // duplicates: of an earlier lane, of a stored hit
+    uint64_t dupU = dups_among(L, accU, keyU, bhU >> 27, lane), dupG = dups_among(L, accG, keyG, bhG >> 27, lane);
+    dupU |= dups_stored(L, st, log, accU & ~dupU, keyU, u1, u2, lane);
+    dupG |= dups_stored(L, st, log, accG & ~dupG, keyG, g1, g2, lane);
+    const uint64_t newU = accU & ~dupU, newG = accG & ~dupG;
+    // the first slot at which a level's total reaches the cap
+    const uint32_t cap = COLD(max_num_hits), spw = COLD(scratch_per_wave);
+    uint32_t xslot = 128, xlevel = 0;
+    {
+        const uint32_t totv = lane < 16 ? L.nhit[0][lane] + L.nhit[1][lane] : 0;
+        for (uint64_t remU = newU, remG = newG; remU | remG;) {
+            const uint32_t w = remU ? rdlane(mmU, __ffsll((unsigned long long)remU) - 1) : rdlane(gsnp, __ffsll((unsigned long long)remG) - 1);
+            const uint64_t mwU = ballot(mmU == w) & newU, mwG = ballot(gsnp == w) & newG;
+            remU &= ~mwU;
+            remG &= ~mwG;
+            const uint32_t tw = rdlane(totv, (int)(w & 15));
+            const uint32_t room = tw < cap ? cap - tw : 1;
+            if ((uint32_t)__popcll(mwU) + (uint32_t)__popcll(mwG) >= room) {
+                const uint32_t pre = (uint32_t)__popcll(mwU & lt) + (uint32_t)__popcll(mwG & lt), inU = (uint32_t)(mwU >> lane) & 1u, inG = (uint32_t)(mwG >> lane) & 1u;
+                const uint64_t hmU = ballot(inU && pre + 1 == room), hmG = ballot(inG && pre + inU + 1 == room);
+                const uint32_t sU = hmU ? 2u * (uint32_t)(__ffsll((unsigned long long)hmU) - 1) : 128u, sG = hmG ? 2u * (uint32_t)(__ffsll((unsigned long long)hmG) - 1) + 1u : 128u;
+                const uint32_t sx = sU < sG ? sU : sG;
+                if (sx < xslot) { xslot = sx; xlevel = w; }
+            }
+        }
+    }
+    // everything up to and including that slot, in slot order
+    const uint32_t xl = xslot >> 1;
+    const uint64_t incl = xslot >= 128 ? ~0ULL : xl < 63 ? (2ULL << xl) - 1 : ~0ULL, excl = xslot >= 128 ? ~0ULL : (1ULL << xl) - 1;
+    const uint64_t uptoU = incl, uptoG = (xslot & 1) || xslot >= 128 ? incl : excl;
+    const uint64_t segU = newU & uptoU, segG = newG & uptoG;
+    if (segU | segG) {
+        const bool mineU = (segU >> lane) & 1, mineG = (segG >> lane) & 1;
+        const uint32_t n0 = st.nlog, cnt = (uint32_t)__popcll(segU) + (uint32_t)__popcll(segG);
+        const uint32_t posU = n0 + (uint32_t)__popcll(segU & lt) + (uint32_t)__popcll(segG & lt), posG = posU + (uint32_t)mineU;
+        if (n0 < 64) {
+            // records 0..63 live in registers, record i in lane i: they get there through the first 64 entries of the survivor list (the batch
+            // being booked has been read into registers: 512 free bytes = 32 records at a time)
+            uint4 *stage = (uint4 *)&L.surv[0];
+#pragma unroll 1
+            for (uint32_t p0 = n0; p0 < 64 && p0 < n0 + cnt; p0 += 32) {
+                wave_sync();
+                if (mineU && posU - p0 < 32u) stage[posU - p0] = make_uint4(hU.w[0], hU.w[1], hU.w[2], hU.w[3]);
+                if (mineG && posG - p0 < 32u) stage[posG - p0] = make_uint4(hG.w[0], hG.w[1], hG.w[2], hG.w[3]);
+                wave_sync();
+                if ((uint32_t)lane - p0 < 32u && (uint32_t)lane < n0 + cnt) {
+                    const uint4 v = stage[(uint32_t)lane - p0];
+                    st.d0 = v.x; st.d1 = v.y; st.d2 = v.z; st.d3 = v.w;
+                }
+            }
+            wave_sync();
+        }
+        const uint64_t inmem = ballot((mineU && posU >= 64 && posU < spw) || (mineG && posG >= 64 && posG < spw));
+        if (inmem) {
+            if (mineU && posU >= 64 && posU < spw) log[posU] = hU.h;
+            if (mineG && posG >= 64 && posG < spw) log[posG] = hG.h;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
+        }
+        if (mineU) {
+            atomicOr(&L.bloom[u1 >> 5], 1u << (u1 & 31));
+            atomicOr(&L.bloom[u2 >> 5], 1u << (u2 & 31));
+            atomicAdd(&L.nhit[chain][mmU & 15], 1u);
+        }
+        if (mineG) {
+            atomicOr(&L.bloom[g1 >> 5], 1u << (g1 & 31));
+            atomicOr(&L.bloom[g2 >> 5], 1u << (g2 & 31));
+            atomicAdd(&L.nhit[chain][gsnp & 15], 1u);
+        }
+        st.nlog = n0 + cnt < spw ? n0 + cnt : spw;
+        wave_sync();
+    }
+    if (xslot >= 128) { pendU = pendG = 0; return BA_DONE; }
+    if (xlevel == 0) return BA_STOP;
+    st.thr = xlevel - 1;
+    pendU &= ~uptoU;
+    pendG &= ~uptoG;
+    return BA_RETHR;
+}
+
+// The HEAVY GAP kernels' survivor stage: the candidates in L.surv[0 .. min(nsurv, 64)) -- their reference planes in one round trip, the
+// ungapped count (CountMismatch*: the bitmap under the valid mask + the N count), the gap search, both hits booked in bulk. Returns true when
+// SnpAlign must stop.
+template <int NWT, bool NEWRULE, class LDS>
+__device__ bool gap_flush(const DevCtx &cx, LDS &L, HitState &st, basal_hit *log, const ReadCtx &rc, uint32_t mode, uint32_t &nsurv, uint32_t r, int lane PH_PARAM) {
+    constexpr int NW = NWT / 2;
+    const uint32_t batch = nsurv < 64 ? nsurv : 64;
+    const bool active = (uint32_t)lane < batch;
+    uint32_t loc = BASAL_REF_MARGIN * 32, strand = 0, hcs = 0, mm = 0xffff;
+    bool alive = false, gap_ok = false;
+#ifdef BASAL_CHECK_FILTER
+    uint32_t chk = 3;
+#endif
+    if (active) {
+        const SurvEnt sv = L.surv[lane];
+        strand = (sv.meta >> 8) & 1;
+        alive = (sv.meta >> 9) & 1;
+        gap_ok = (sv.meta >> 10) & 1;
+#ifdef BASAL_CHECK_FILTER
+        chk = (sv.meta >> 11) & 3u;
+#endif
+        loc = sv.loc;
+        if (((unsigned long long)(loc >> 5) + NWT + 4) >= COLD(nwords)) loc = (uint32_t)guard_idx(cx, G_XREF, loc, 0, r) + BASAL_REF_MARGIN * 32;
+        hcs = L.ent[sv.meta & 0xff].hcs;
+    }
+    const uint32_t chain = (hcs >> 16) & 1;
+    const uint64_t(*M)[NW + 2] = L.mmp[chain];
+    // the candidate's reference bases from start - g on, as planes in the read's frame: NW + 2 blocks of 64 bases cover the read at every shift
+    uint64_t Rh[NW + 1], Rl[NW + 1], D0[NW];
+    {
+        const uint32_t first = loc - cx.gap, rel = first & 63;  // loc >= 12320 by construction
+        const ulonglong2 *P = (strand ? cx.xpl[1] : cx.xpl[0]) + (first >> 6);
+        const uint32_t nblk = active ? ((rel + rc.len + 2 * cx.gap + 63) >> 6) : 0;
+        ulonglong2 B[NW + 2];
+#pragma unroll
+        for (int i = 0; i < NW + 2; i++) {
+            B[i] = make_ulonglong2(0, 0);
+            if ((uint32_t)i < nblk) B[i] = P[i];
+        }
+#pragma unroll
+        for (int w = 0; w <= NW; w++) { Rh[w] = funnel64(B[w].x, B[w + 1].x, rel); Rl[w] = funnel64(B[w].y, B[w + 1].y, rel); }
+    }
+    plane_bitmap<NW>(Rh, Rl, cx.gap, M, D0);
+    if (alive) {
+        mm = rc.n_count;
+#pragma unroll
+        for (int w = 0; w < NW; w++) mm += popc64(D0[w] & L.valp[chain][w + 1]);
+    }
+    PH(PH_SCORE);
+#ifdef BASAL_CHECK_FILTER
+    if (active && mm <= st.thr && !(chk & 1)) guard_idx(cx, G_WATCHDOG, 0x20000u | mm, 0, r);
+#endif
+    uint64_t pendU = ballot(active && alive), pendG = ballot(active && gap_ok);
+    bool stop = false;
+    for (uint32_t spin = 0;; spin++) {
+        if (spin > 160) { guard_idx(cx, G_WATCHDOG, 0x50000u | spin, 0, r); stop = true; break; }
+        bool gfound = false;
+        uint32_t gsnp = 0, gpos = 0;
+        int gshift = 0;
+        if ((pendG >> lane) & 1) gfound = gap_search<NW>(cx, Rh, Rl, M, D0, rc, st.thr, hcs & 0xffffu, gsnp, gpos, gshift);
+#ifdef BASAL_CHECK_FILTER
+        if (gfound && !(chk & 2)) guard_idx(cx, G_WATCHDOG, 0x30000u | (gsnp << 8) | (uint32_t)(gshift & 0xff), 0, r);
+#endif
+        PH(PH_REPLAY);
+        const int rcode = bulk_add2(cx, L, st, log, rc, pendU, pendG, loc, strand, chain, mm, gfound, gsnp, gpos, gshift, mode, r, lane);
+        PH(PH_E1);
+        if (rcode == BA_STOP) { stop = true; break; }
+        if (rcode == BA_DONE) break;
+    }
+    const uint32_t rest = nsurv - batch;  // drop the batch from the front of the list
+    SurvEnt v = {0, 0};
+    if ((uint32_t)lane < rest) v = L.surv[batch + lane];
+    wave_sync();
+    if ((uint32_t)lane < rest) L.surv[lane] = v;
+    nsurv = rest;
+    wave_sync();
+    return stop;
+}
+
 // A window of the HEAVY kernels' stream test. The flank words of a core that keeps long lists are stored as bit planes (basal_bits.h
 // split_planes: the high bits of the 32 base codes in the upper half, the low bits in the lower), and what depends on the read alone is folded
 // into four 32-bit words, so that cmp_word's rule (basal_bits.h; CountMismatch / CountMismatch_new, align.h:126-128, 210-219) costs a
@@ -1451,7 +1874,6 @@ template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
 __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
                              const uint32_t *pre, int pre_c, int lane PH_PARAM) {
     using LDS = WaveLds<NWT, GAP, HEAVY>;
-    static_assert(!(GAP && HEAVY), "the HEAVY path is the non-GAP kernels'");
     const bool allmodes = (rd.readset & BASAL_READ_ALLMODES) != 0;  // a PE mate: PairAlign::RunAlign drives the modes
     rd.readset &= 0x7f;
     basal_result res;
@@ -1559,7 +1981,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
             if ((unsigned long long)e_off + e_m > COLD(nlocs)) e_off = guard_u32(cx, G_LOCS, e_off + e_m, 0, r);
             SeedEntT<GAP> e;
             e.off = e_off; e.m = e_m; e.nfwd = e_nfwd; e.jj0 = e_jj0; e.pre = inc - e_m; e.hcs = e_h | (e_chain << 16) | (side << 17);
-            if constexpr (HEAVY) {  // the flank words of such a core are bit planes: the read's window likewise (win_make)
+            if constexpr (HEAVY && !GAP) {  // the flank words of such a core are bit planes: the read's window likewise (win_make)
                 const WinP k = win_make<NEWRULE>(wr, wm, wc);
                 e.fr = (uint64_t)k.rh << 32 | k.rl; e.fm = (uint64_t)k.x << 32 | k.m; e.fc = 0;
             } else if constexpr (!GAP) { e.fr = wr; e.fm = wm; e.fc = wc; }
@@ -1582,7 +2004,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
         const uint32_t T = rdlane(inc, (int)nent - 1);
         PH(PH_MODE);
 
-        if constexpr (HEAVY) {
+        if constexpr (HEAVY && !GAP) {
             done = heavy_mode<NWT, NEWRULE>(cx, L, st, log, rc, mode, inc, e_m, nent, T, r, lane PH_ARG);
         } else {
         // Non-GAP: 64 candidates of the stream per iteration. GAP: the flank tests run on the stream, the candidates they
@@ -1669,6 +2091,10 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                     t0 += 64;
                     wave_sync();
                     if (t0 < T && nsurv < 64) continue;
+                }
+                if constexpr (HEAVY) {  // the survivors' stage on bit planes, both hits of a candidate booked in bulk
+                    if (nsurv) done = gap_flush<NWT, NEWRULE>(cx, L, st, log, rc, mode, nsurv, r, lane PH_ARG);
+                    continue;
                 }
                 batch = nsurv < 64 ? nsurv : 64;
                 if (batch == 0) continue;
@@ -1933,8 +2359,15 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
 #ifndef BASAL_W4H
 #define BASAL_W4H 5  // HEAVY: 96 registers for the two-chunk long-list loop (heavy_mode); six waves with 80: 132 against 125 ms per 10 M reads
 #endif
+#ifndef BASAL_W4GH
+#define BASAL_W4GH 4  // HEAVY GAP: the Bloom filter and the buckets on top of the GAP kernels' LDS leave room for four blocks per CU
+#endif
+#ifndef BASAL_W8GH
+#define BASAL_W8GH 3
+#endif
 constexpr int waves_per_simd(int nwt, bool gap, bool heavy = false) {
     // (HEAVY with longer reads: the survivor list and the Bloom filter leave the LDS room for 4 / 3 blocks per CU)
+    if (gap && heavy) return nwt == 4 ? BASAL_W4GH : nwt == 8 ? BASAL_W8GH : 2;
     return nwt == 4 ? (gap ? BASAL_W4G : heavy ? BASAL_W4H : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : heavy ? 4 : BASAL_W8NG) : (gap ? BASAL_W16G : heavy ? 3 : BASAL_W16NG);
 }
 
@@ -1942,6 +2375,14 @@ template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
 __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_kernel(DevCtx cx) {
     __shared__ uint8_t s_tab[5 * 256];
     __shared__ WaveLds<NWT, GAP, HEAVY> s_w[4];
+#ifdef BASAL_CHECK_FILTER  // the check build: BASAL_POISON=<byte> fills the block's LDS first -- no result may depend on what LDS held at launch
+    if (COLD(lds_poison) >> 8) {
+        const uint32_t pat = (COLD(lds_poison) & 0xffu) * 0x01010101u;
+        for (uint32_t i = threadIdx.x; i < sizeof(s_w) / 4; i += 256) ((uint32_t *)s_w)[i] = pat;
+        if (threadIdx.x < 64) { s_anchor[threadIdx.x] = s_rcoff[threadIdx.x] = s_csize[threadIdx.x] = pat; }
+        __syncthreads();
+    }
+#endif
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
     s_prof[threadIdx.x >> 4][threadIdx.x & 15] = (uint16_t)profile(threadIdx.x >> 4, threadIdx.x & 15, cx.K, cx.I);
     if (threadIdx.x >= 1 && threadIdx.x <= 16) s_rcp[threadIdx.x] = (65536u + threadIdx.x - 1) / threadIdx.x;
@@ -2076,7 +2517,8 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
 typedef void (*kernel_fn)(DevCtx);
 template <int NWT>
 kernel_fn pick_kernel(bool newrule, bool gap, bool heavy = false) {
-    if (heavy && !gap) return newrule ? align_kernel<NWT, true, false, true> : align_kernel<NWT, false, false, true>;
+    if (heavy && gap) return newrule ? align_kernel<NWT, true, true, true> : align_kernel<NWT, false, true, true>;
+    if (heavy) return newrule ? align_kernel<NWT, true, false, true> : align_kernel<NWT, false, false, true>;
     if (newrule) return gap ? align_kernel<NWT, true, true, false> : align_kernel<NWT, true, false, false>;
     return gap ? align_kernel<NWT, false, true, false> : align_kernel<NWT, false, false, false>;
 }
@@ -2135,7 +2577,7 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
 extern "C" void basal_core_destroy(basal_core_t *c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
+    hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_xpl[0]); hipFree(c->d_xpl[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_seedw); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_names); hipFree(c->d_name_off);
     hipFree(c->d_pe_pairs); hipFree(c->d_pe_recs); hipFree(c->d_pe_work); hipFree(c->d_pe_misc);
@@ -2152,6 +2594,23 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     if (c->ev3) hipEventDestroy(c->ev3);
     delete c;
 }
+
+// GAP cores: the staged strands once more as bit planes, one 16-byte block per 64 bases (DevCtx::xpl)
+namespace {
+__global__ __launch_bounds__(256) void ref_to_planes(const uint64_t *__restrict__ x, unsigned long long nwords_alloc, ulonglong2 *__restrict__ pl, unsigned long long nblk) {
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (unsigned long long)gridDim.x * blockDim.x) {
+        uint64_t hi = 0, lo = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint64_t v = 2 * b + k < nwords_alloc ? x[2 * b + k] : 0;  // base j at bits 63-2j (high), 62-2j (low)
+            const uint64_t rv = __brevll(v);                                     // base j: high bit at 2j, low bit at 2j+1
+            hi |= (uint64_t)even_bits(rv) << (32 * k);
+            lo |= (uint64_t)even_bits(rv >> 1) << (32 * k);
+        }
+        pl[b] = make_ulonglong2(hi, lo);
+    }
+}
+}  // namespace
 
 extern "C" int basal_core_set_reference(basal_core_t *c, const uint64_t *xref_fwd, const uint64_t *xref_rc, uint64_t nwords, const uint32_t *ref_anchor,
                                         const uint32_t *contig_size, const uint32_t *rc_offset, uint32_t ncontig) {
@@ -2178,6 +2637,18 @@ extern "C" int basal_core_set_reference(basal_core_t *c, const uint64_t *xref_fw
     HIP_TRY(hipMemcpy(c->d_anchor, ref_anchor, (ncontig + 1) * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_size, contig_size, ncontig * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_rcoff, rc_offset, ncontig * 4, hipMemcpyHostToDevice));
+    hipFree(c->d_xpl[0]); hipFree(c->d_xpl[1]);
+    c->d_xpl[0] = c->d_xpl[1] = nullptr;
+    if (c->p.gap > 0) {
+        const unsigned long long nblk = (nwords + 64) / 2 + 8;
+        for (int s = 0; s < 2; s++) {
+            HIP_TRY(hipMalloc(&c->d_xpl[s], nblk * sizeof(ulonglong2)));
+            hipLaunchKernelGGL(ref_to_planes, dim3((unsigned)std::min<unsigned long long>((nblk + 255) / 256, 65536ull)), dim3(256), 0, 0, c->d_xref[s],
+                               (unsigned long long)(nwords + 64), c->d_xpl[s], nblk);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipDeviceSynchronize());
+    }
     c->nwords = nwords;
     c->ncontig = ncontig;
     c->have_ref = true;
@@ -2255,7 +2726,7 @@ extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_
     if (lds_bytes) {
         int nwt = c->nwt ? c->nwt : 4;
         bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
-        const bool hv = c->heavy && !gp;
+        const bool hv = c->heavy;
         kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv) : nwt == 8 ? pick_kernel<8>(nr, gp, hv) : pick_kernel<16>(nr, gp, hv);
         hipFuncAttributes at;
         HIP_TRY(hipFuncGetAttributes(&at, (const void *)k));
@@ -2300,6 +2771,11 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         cx.win2_min_T = c->max_kmer_num >= min_cut ? min_T : 0xFFFFFFFFu;
     }
     cx.flank_a = c->d_flank_a; cx.flank_b = c->d_flank_b; cx.seedw = c->d_seedw;
+    cx.xpl[0] = c->d_xpl[0]; cx.xpl[1] = c->d_xpl[1];
+    {
+        static const char *pz = getenv("BASAL_POISON");
+        cx.lds_poison = pz ? 0x100u | (uint32_t)(strtol(pz, nullptr, 0) & 0xff) : 0;
+    }
     cx.K = c->p.seed_size; cx.I = c->p.index_interval; cx.max_num_hits = c->p.max_num_hits; cx.chains = c->p.chains;
     cx.randseed = c->p.randseed; cx.gap = c->p.gap; cx.gap_edge = c->p.gap_edge; cx.n_mis = c->p.n_mis;
     cx.stream_mode = (uint32_t)stream_mode; cx.report_repeat_hits = c->p.report_repeat_hits;
@@ -2319,7 +2795,7 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     int nwt = max_len <= 128 ? 4 : max_len <= 256 ? 8 : 16;
     c->nwt = nwt;
     bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
-    const bool hv = c->heavy && !gp;
+    const bool hv = c->heavy;
     {
         const char *e = getenv("BASAL_HEAVY_M");  // (tests: 1 sends every list through the long-list loop)
         cx.heavy_m = e ? (uint32_t)atoi(e) : 128u;

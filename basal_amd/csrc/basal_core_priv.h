@@ -29,6 +29,7 @@ struct basal_core {
     hipDeviceProp_t prop;
     // reference + index in HBM
     uint64_t *d_xref[2] = {nullptr, nullptr};
+    ulonglong2 *d_xpl[2] = {nullptr, nullptr};  // GAP cores: the strands as bit planes, 16 bytes per 64 bases (the HEAVY GAP kernels' gap search reads them)
     uint64_t nwords = 0;
     uint32_t *d_anchor = nullptr, *d_size = nullptr, *d_rcoff = nullptr;
     uint32_t ncontig = 0;

@@ -186,6 +186,9 @@ int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys) {
                                c->total_kmers, c->p.seed_size, stride, c->d_flank_a);
         HIP_TRYI(hipGetLastError());
         HIP_TRYI(hipDeviceSynchronize());
+        // (the same rule as below picks the HEAVY GAP kernels: the survivors' stage on bit planes, hits booked in bulk; the flank layout is the GAP kernels')
+        const char *e = getenv("BASAL_HEAVY");
+        c->heavy = e ? atoi(e) != 0 : c->max_kmer_num >= 32768;
         return BASAL_OK;
     }
     // Long lists are the rule where the over-represented-k-mer cut-off is high (a repeat-rich genome: 107 091 on the hg38-like stand-in,

@@ -80,6 +80,7 @@ struct basal_multi {
         unsigned int *counter = nullptr;
     };
     std::vector<Dev> dev;
+    std::vector<uint64_t> h2d_bytes;  // per GPU: what the last batch copied to it (basal_multi_last_h2d_bytes)
     // on GPU 0: every rank's records / streams, rank-major
     basal_result *g_results = nullptr; size_t cap_g_results = 0;
     basal_hit *g_stream = nullptr; size_t cap_g_stream = 0;
@@ -138,6 +139,7 @@ extern "C" int basal_multi_create(const basal_params *p, const int *devices, int
 }
 
 extern "C" int basal_multi_ndev(const basal_multi_t *m) { return m ? m->n : 0; }
+extern "C" uint64_t basal_multi_last_h2d_bytes(const basal_multi_t *m, int rank) { return m && rank >= 0 && rank < m->n && (size_t)rank < m->h2d_bytes.size() ? m->h2d_bytes[(size_t)rank] : 0; }
 extern "C" basal_core_t *basal_multi_core(basal_multi_t *m, int rank) { return m && rank >= 0 && rank < m->n ? m->cores[(size_t)rank] : nullptr; }
 
 // the whole reference + index on every GPU
@@ -172,8 +174,8 @@ static int grow_dev(T *&p, size_t &cap, size_t need) {
     return BASAL_OK;
 }
 
-// basal_core_align_batch over all GPUs: same arguments, same results. Every GPU receives the batch's bases, descriptors and stale table
-// (a read may inherit its start offset from a read of another shard), aligns its own range of reads, and GPU 0 gathers the records.
+// basal_core_align_batch over all GPUs: same arguments, same results. Every GPU receives the bases, descriptors and stale entries of its own
+// range of reads (and of the reads those inherit a start offset from, which may lie in another shard), aligns that range, and GPU 0 gathers the records.
 extern "C" int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, const basal_stale *stales,
                                        uint32_t nstale, int stream_mode, basal_result *results, basal_hit *stream, uint64_t stream_cap, uint64_t *stream_used,
                                        uint8_t carry[2][2]) {
@@ -189,6 +191,7 @@ extern "C" int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, u
     const uint64_t stream_cap_dev = stream_mode == BASAL_STREAM_NONE ? 0 : (stream_cap + (uint64_t)N - 1) / (uint64_t)N + 1024;
     std::vector<uint32_t> iota(n);
     for (uint32_t i = 0; i < n; i++) iota[i] = i;
+    m->h2d_bytes.assign((size_t)N, 0);
     // 1. inputs to every GPU, each GPU's launch on its own stream
     for (int d = 0; d < N; d++) {
         basal_multi::Dev &v = m->dev[(size_t)d];
@@ -200,9 +203,31 @@ extern "C" int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, u
             (stream_cap_dev && (rc = grow_dev(v.stream, v.cap_stream, (size_t)stream_cap_dev)))) return rc;
         uint64_t lo, hi;
         basal_shard_range(n, (uint32_t)d, (uint32_t)N, &lo, &hi);
-        HIP_TRYM(hipMemcpyAsync(v.bases, bases, nbases, hipMemcpyHostToDevice, v.st));
-        HIP_TRYM(hipMemcpyAsync(v.reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, v.st));
-        if (nstale) HIP_TRYM(hipMemcpyAsync(v.stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, v.st));
+        // H2D per GPU = what its shard needs, at the offsets the whole batch would have: the bases, descriptors and stale entries of its own
+        // reads and of the earlier reads they inherit a start offset from (basal_stale.src may name a read of another shard)
+        if (hi > lo) {
+            uint64_t b0 = ~0ull, b1 = 0, d0 = lo, s0 = ~0ull, s1 = 0;
+            auto need = [&](uint32_t i) {
+                const basal_read &r = reads[i];
+                if (r.len == 0) return;
+                b0 = std::min<uint64_t>(b0, r.seq_off);
+                b1 = std::max<uint64_t>(b1, (uint64_t)r.seq_off + r.len);
+            };
+            for (uint64_t i = lo; i < hi; i++) {
+                need((uint32_t)i);
+                const basal_read &r = reads[i];
+                if (r.len && r.stale_idx != BASAL_STALE_NONE && stales) {
+                    s0 = std::min<uint64_t>(s0, r.stale_idx);
+                    s1 = std::max<uint64_t>(s1, (uint64_t)r.stale_idx + 1);
+                    const uint32_t src = stales[r.stale_idx].src;
+                    if (src != BASAL_STALE_CARRY && src < i) { need(src); d0 = std::min<uint64_t>(d0, src); }
+                }
+            }
+            if (b1 > b0) HIP_TRYM(hipMemcpyAsync(v.bases + b0, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, v.st));
+            HIP_TRYM(hipMemcpyAsync(v.reads + d0, reads + d0, (size_t)(hi - d0) * sizeof(basal_read), hipMemcpyHostToDevice, v.st));
+            if (s1 > s0) HIP_TRYM(hipMemcpyAsync(v.stales + s0, stales + s0, (size_t)(s1 - s0) * sizeof(basal_stale), hipMemcpyHostToDevice, v.st));
+            m->h2d_bytes[(size_t)d] = (b1 > b0 ? b1 - b0 : 0) + (hi - d0) * sizeof(basal_read) + (s1 > s0 ? (s1 - s0) * sizeof(basal_stale) : 0);
+        } else m->h2d_bytes[(size_t)d] = 0;
         if (hi > lo) HIP_TRYM(hipMemcpyAsync(v.order, iota.data() + lo, (size_t)(hi - lo) * 4, hipMemcpyHostToDevice, v.st));
         HIP_TRYM(hipMemsetAsync(v.used, 0, 8, v.st));
         HIP_TRYM(hipMemsetAsync(v.results + lo, 0, (size_t)shard_cap * sizeof(basal_result) <= (v.cap_results - lo) * sizeof(basal_result) ? (size_t)shard_cap * sizeof(basal_result) : (size_t)(hi - lo) * sizeof(basal_result), v.st));

@@ -315,6 +315,8 @@ int basal_multi_create(const basal_params *p, const int *devices, int ndev, basa
 void basal_multi_destroy(basal_multi_t *m);
 int basal_multi_ndev(const basal_multi_t *m);
 basal_core_t *basal_multi_core(basal_multi_t *m, int rank);
+/* Instrumentation: the bytes the last basal_multi_align_batch copied to GPU `rank` (its shard's bases, descriptors and stale entries). */
+uint64_t basal_multi_last_h2d_bytes(const basal_multi_t *m, int rank);
 int basal_multi_upload(basal_multi_t *m, const basal_ref_t *r, int build_index_on_gpu, uint32_t *max_kmer_num); /* basal_host_ref_upload on every GPU */
 /* basal_core_align_batch over all GPUs: same arguments, same results. */
 int basal_multi_align_batch(basal_multi_t *m, const uint8_t *bases, uint64_t nbases, const basal_read *reads, uint32_t n, const basal_stale *stales,

@@ -39,6 +39,12 @@ def test_multi_align_batch_equals_core_align_batch(name, mode):
         assert np.array_equal(got[f], want[f]), f
     hit = want["best_level"] != 0xFF
     assert got["best"][hit].tobytes() == want["best"][hit].tobytes()
+    # each GPU is sent what its shard needs and no more: with one rank that is every read's bases once, the descriptors and the stale entries in use
+    live = descs["len"] > 0
+    used = descs["stale_idx"][live & (descs["stale_idx"] != B.STALE_NONE)]
+    span = int((descs["seq_off"][live].astype(np.int64) + descs["len"][live]).max() - descs["seq_off"][live].min())
+    want_bytes = span + len(descs) * 16 + (int(used.max() - used.min() + 1) * 124 if len(used) else 0)
+    assert B.lib().basal_multi_last_h2d_bytes(multi.h, 0) == want_bytes
     if mode != B.STREAM_NONE:  # the same records per read (stream positions may differ)
         for g, w in zip(got, want):
             a = gstream[g["stream_first"]: g["stream_first"] + g["stream_n"]].tobytes()

@@ -43,8 +43,15 @@ CONFIGS = {
     "c2_realistic_heavy_150": ("C:T", ["-M", "C:T", "-S", "1"], 150, 100_000, 0.95, 0.01, None, dict(realistic=True, scale=0.4, min_cutoff=32768)),
     "c5_realistic_heavy": ("T:-", ["-M", "T:-", "-S", "1"], 100, 60_000, 0.0, 0.01, dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80),
                            dict(realistic=True, scale=0.4, min_cutoff=32768)),
+    # configs 4 and 5p on a genome whose own cut-off selects the HEAVY GAP kernels (<4,true,true,HEAVY>: the survivors' stage on bit planes, both
+    # hits of a candidate booked in bulk), and the 150-base form of it (<8,*,true,HEAVY>)
+    "c4_realistic_heavy": ("A:CGT", ["-M", "A:CGT", "-S", "1", "-g", "2"], 100, 40_000, 0.3, 0.01, dict(conv_from=0, conv_to=[1, 2, 3], p_conv=0.3, indel_frac=0.01, indel_max=2),
+                           dict(realistic=True, scale=0.4, min_cutoff=32768)),
+    "c5p_realistic_heavy": ("T:-", ["-M", "T:-", "-S", "1", "-n", "1", "-g", "3"], 100, 30_000, 0.0, 0.01, dict(conv_from=3, conv_to=3, p_conv=0.0, del_base=3, del_frac=0.3, del_lo=20, del_hi=80),
+                            dict(realistic=True, scale=0.4, min_cutoff=32768)),
+    "ct_150_g2_realistic_heavy": ("C:T", ["-M", "C:T", "-S", "1", "-g", "2"], 150, 30_000, 0.95, 0.01, dict(indel_frac=0.05, indel_max=2), dict(realistic=True, scale=0.4, min_cutoff=32768)),
 }
-RELAXED = ("c4_acgt_g2", "c4_acgt_g2_8d", "c4_realistic")  # A:CGT: see the comment in the test
+RELAXED = ("c4_acgt_g2", "c4_acgt_g2_8d", "c4_realistic", "c4_realistic_heavy")  # A:CGT: see the comment in the test
 
 
 def setup(name, scale=0.02, n_reads=None):
@@ -145,17 +152,20 @@ def test_config_matches_oracle_on_sample_and_properties(name):
 
 def test_gap_bounds_check_build_at_scale():
     """The `chk` twin of the library (every candidate of the GAP kernels scored exactly; the launch fails if the stream's bounds would have
-    dropped an accepted one) on config 4's SURVEY 8d reads at scale, results = the oracle's on the sample.  (A library is loaded once per
-    process, hence the child.)"""
+    dropped an accepted one) on config 4's SURVEY 8d reads at scale and on configs 4 / 5p on the genome whose cut-off selects the HEAVY GAP
+    kernels, results = the oracle's on the sample.  (A library is loaded once per process, hence the child.)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(["make", "-C", os.path.join(root, "basal_amd", "csrc"), "chk"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    env = dict(os.environ, BASAL_LIB=os.path.join(root, "basal_amd", "lib", "libbasal_amd_chk.so"))
+    chk = os.path.join(root, "basal_amd", "lib", "libbasal_amd_chk.so")
+    if not os.path.exists(chk):  # (shipped prebuilt with the snapshot; built here only if it is missing)
+        r = subprocess.run(["make", "-C", os.path.join(root, "basal_amd", "csrc"), "chk"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, BASAL_LIB=chk)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "test_config_matches_oracle_on_sample_and_properties and (c4_acgt_g2_8d or ct_150_g2)"], capture_output=True, text=True, env=env, cwd=root)
+                        "-k", "test_config_matches_oracle_on_sample_and_properties and (c4_acgt_g2_8d or ct_150_g2] or c4_realistic_heavy or c5p_realistic_heavy)"],
+                       capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert "2 passed" in r.stdout, r.stdout[-500:]
+    assert "4 passed" in r.stdout, r.stdout[-500:]
 
 
 def test_read_order_independence():
