@@ -573,6 +573,10 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
                   "parse it on the host and submit it with basal_pipe_submit_records");
         ret = BASAL_EIO;
     }
+    if (!ret && sam && (s.h_cnt->irregular & 4u)) {
+        set_error("pipe: batch " + std::to_string(s.batch_no) + " did not start from the state the batch before it left (carry hand-over out of order): internal error");
+        ret = BASAL_EDEVICE;
+    }
     if (!ret && sam && s.h_cnt->pair_err) {
         set_error("Error: Paired reads name not match (pair " + std::to_string(s.h_cnt->pair_err_at) + " of the batch): the reference exits here (pairs.cpp:501-504)");
         ret = BASAL_EINVAL;

@@ -38,7 +38,9 @@ struct CarryRead {
 struct CarryState {
     uint32_t depth[2];
     uint32_t next_index;  // the global read number the next batch starts at (text form: only the device has counted the reads)
-    uint32_t pad;
+    uint32_t seq;         // the number of the batch this state is the start of: carry_update checks that batch b really starts from the state batch b - 1 left
+                          // (a hand-over between streams or GPUs that ran out of order would otherwise show only as a different read number -- a different
+                          // rotation start and pick for reads with several equally good hits -- in one batch)
     CarryRead ghost[2];             // last defining read per slot (valid = 0: none yet)
     CarryRead stack[2][kStackMax];  // [slot][0] = most recent
 };
@@ -50,7 +52,8 @@ struct BatchCounters {
     unsigned long long stream_used;  // hit-stream records used by the align kernels (-r 2)
     uint32_t n_reads;                // reads in the batch (device-parsed text: known here first)
     uint32_t n_lines;
-    uint32_t irregular;              // text form: the text is not 4 (2) regular lines per record
+    uint32_t irregular;              // bit 0: text form, the text is not 4 (2) regular lines per record; bit 1: a hit stream overflowed; bit 2: the carry state this batch
+                                     // started from was not the one the batch before it left (CarryState::seq)
     uint32_t n_stale;
     uint32_t cls_n[3];               // reads per length class
     uint32_t pair_err;               // paired-end: a pair whose names differ from the first character on (FixPairReadName exits there) ...

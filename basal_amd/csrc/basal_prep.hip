@@ -396,11 +396,15 @@ __global__ __launch_bounds__(256) void reverse_npos(const uint16_t *__restrict__
 __global__ __launch_bounds__(512) void carry_update(const uint8_t *__restrict__ text, const basal_read *__restrict__ desc, const uint16_t *__restrict__ npos,
                                                     const int32_t *__restrict__ defscan, const int32_t *__restrict__ defidx_raw, const uint32_t *__restrict__ n_ptr,
                                                     uint32_t n_host, uint32_t max_reads, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
-                                                    const CarryState *__restrict__ in, CarryState *__restrict__ out) {
+                                                    const CarryState *__restrict__ in, CarryState *__restrict__ out, uint32_t batch_no, BatchCounters *__restrict__ cnt) {
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     __shared__ uint32_t s_r[kStackMax], s_sorted[kStackMax];
     __shared__ uint32_t s_keep_from, s_new;
-    if (threadIdx.x == 0) out->next_index = n ? desc[n - 1].index + 1 : in->next_index;
+    if (threadIdx.x == 0) {
+        out->next_index = n ? desc[n - 1].index + 1 : in->next_index;
+        out->seq = batch_no + 1;
+        if (in->seq != batch_no) atomicOr(&cnt->irregular, 4u);  // not the state batch_no - 1 left: the pipe reports it (basal_pipe_collect)
+    }
     for (uint32_t slot = 0; slot < 2; slot++) {
         uint32_t m = list_n[slot];
         if (m > (uint32_t)kStackMax) m = kStackMax;
@@ -913,7 +917,7 @@ int prep_enqueue_filter(basal_core *c, const PrepConst &k, SlotDev &s, const Pre
     uint32_t *list = s.order + (size_t)3 * max_reads, *list_n = list + 2 * kStackMax;
     HIP_TRYP(hipMemsetAsync(list_n, 0, 2 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(stack_collect, dim3(grid_for(max_reads, 256, c)), dim3(256), 0, st, s.npos, sufmax, n_ptr, n_host, max_reads, list, list_n);
-    hipLaunchKernelGGL(carry_update, dim3(1), dim3(512), 0, st, s.text, s.desc, s.npos, defscan, s.defidx, n_ptr, n_host, max_reads, list, list_n, cin, cout);
+    hipLaunchKernelGGL(carry_update, dim3(1), dim3(512), 0, st, s.text, s.desc, s.npos, defscan, s.defidx, n_ptr, n_host, max_reads, list, list_n, cin, cout, batch_no, s.cnt);
     HIP_TRYP(hipGetLastError());
     return BASAL_OK;
 }

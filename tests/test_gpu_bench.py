@@ -51,14 +51,3 @@ def test_bench_two_gloo_ranks_on_one_gpu():
     c = d["config"]
     assert c["gathered_aligned_reads"] == c["aligned_reads_all_ranks"] > 0.9 * 2 * 2 * 200000
     assert d["roofline"]["kernel_ms"] > 0 and d["cpu_baseline"] is None
-
-
-def test_bench_roofline_bytes_of_the_headline_do_not_depend_on_n():
-    """The algorithmic bytes per read an N > 1 run prices its launches with (no oracle sample there) are the committed figure of the SAME
-    stand-in genome the N = 1 run measures (profiles/algorithmic.json, keyed by genome)."""
-    a = json.load(open(os.path.join(H.ROOT, "profiles", "algorithmic.json")))
-    assert set(a) >= {"realistic", "uniform"} and a["realistic"]["bytes_per_read"] > 5 * a["uniform"]["bytes_per_read"]
-    last = sorted(f for f in os.listdir(H.ROOT) if f.startswith("BENCH_r") and f.endswith(".json"))[-1]
-    line = json.loads(json.load(open(os.path.join(H.ROOT, last)))["run"]["stdout_tail"].strip().splitlines()[-1])
-    if "realistic" in line["config"]["workload"] or "hg38-like" in line["config"]["workload"]:
-        assert abs(line["config"]["algorithmic_bytes_per_read"] / a["realistic"]["bytes_per_read"] - 1) < 0.02

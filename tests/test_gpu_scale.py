@@ -179,22 +179,40 @@ def test_read_order_independence():
     assert res_p.tobytes() == res[perm].tobytes()
 
 
-def test_full_size_properties():
-    """BASELINE.json config 2 at its full genome size (hg38-sized stand-in, 3.09 Gbp, 1.5 G index entries) and 2 M reads:
-    too large for the oracle to check read by read, so the size-independent properties carry it -- planted positions are
-    recovered, strands are right, batching does not matter, a second run is identical.  (bench.py checks a 400 000-read
-    sample of the same workload against the oracle on every default run.)"""
-    p, flags, G, words, sizes, core, hb, descs, (ci, start, rev) = setup("c2_ct_g0", scale=1.0, n_reads=2_000_000)
+@pytest.mark.parametrize("realistic", [False, True])
+def test_full_size_properties(realistic):
+    """BASELINE.json config 2 at its full genome size (hg38-sized stand-in, 3.09 Gbp, 1.5 G index entries) and 2 M reads, on the uniform
+    stand-in (standard kernel) and on the hg38-like repeat landscape -- the bench line's workload, where the index's own cut-off selects the
+    HEAVY kernels: too large for the oracle to check read by read, so the size-independent properties carry it -- planted positions are
+    recovered, strands are right, batching does not matter, a second run is identical -- and a 100 000-read sample goes through the oracle on
+    the same index.  (bench.py checks a 400 000-read sample of the same workload against the oracle on every default run.)"""
+    import oracle_bridge
+    CONFIGS["_full"] = ("C:T", ["-M", "C:T", "-S", "1"], 100, 2_000_000, 0.95, 0.01, None, dict(realistic=realistic, scale=1.0, min_cutoff=32768 if realistic else 0))
+    try:
+        p, flags, G, words, sizes, core, hb, descs, (ci, start, rev) = setup("_full")
+    finally:
+        del CONFIGS["_full"]
     res = run(core, hb, descs)
+    if realistic:  # the HEAVY instantiation is the one that ran
+        assert os.environ.get("BASAL_HEAVY", "1") != "0"
+        assert core.launch_info()[2] > 25000, "LDS per block of the HEAVY kernels (Bloom filter + survivor list)"
     aligned = res["best_level"] != 0xFF
     assert aligned.mean() > 0.999
     uniq = aligned & (res["n_hit"].astype(np.uint32) + res["n_chit"] == 1)
-    assert uniq.mean() > 0.99
+    assert uniq.mean() > (0.95 if realistic else 0.99)  # (reads from young repeat copies are legitimately multiple)
     ok = (res["best"]["chr"] >> 1 == ci) & (res["best"]["loc"] == start)
-    assert ok[uniq].mean() > 0.999
+    assert ok[uniq].mean() > (0.995 if realistic else 0.999)
     assert ((res["best"]["chr"] & 1) == rev)[uniq & ok].all()
     assert run(core, hb, descs, split=333_333).tobytes() == res.tobytes()
     assert run(core, hb, descs).tobytes() == res.tobytes()
+    # a 100 000-read sample against the oracle on the same index (downloaded from the GPU)
+    n, ns, rl = len(descs), 100_000, int(descs["len"][0])
+    ob = oracle_bridge.OracleOnIndex(core, p, flags, G.names, sizes, words)
+    sel = np.linspace(0, n - 1, ns).astype(np.int64)
+    sb = np.concatenate([hb[i * rl:(i + 1) * rl] for i in sel])
+    best, _, _ = ob.align(sb, np.arange(ns, dtype=np.uint32) * rl, descs["len"][sel], descs["index"][sel], descs["max_snp"][sel], 16)
+    bad = oracle_bridge.differing(res[sel], best)
+    assert len(bad) == 0, "reads %s differ from the oracle" % sel[bad][:10]
 
 
 def _host_ref_from_genome(p, G, tmp):
