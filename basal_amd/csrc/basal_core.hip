@@ -238,6 +238,19 @@ struct GapLds<NWT, true> {
     uint64_t mmp[2][4][NWT / 2 + 2];
     uint64_t valp[2][NWT / 2 + 2];
 };
+// HEAVY GAP kernels: per seed of the mode, which bits of its two windows are among the read's first / last gap_edge bases. GapAlign never puts
+// the gap inside those (align.cpp:385, 391): the first gap_edge bases always align at the candidate's start and the last gap_edge at the
+// shifted start, so there a mismatch counts even if the other start matches -- the stream's bound (iii) with teeth for diverged copies.
+struct SeedEndMask {
+    uint64_t fl, el;  // long window: bits among the read's first / last gap_edge bases
+    uint32_t fs, es;  // short window
+};
+template <bool ON>
+struct EndLds {};
+template <>
+struct EndLds<true> {
+    SeedEndMask entx[32];
+};
 // the candidates the stream's tests could not rule out, in visitation order (GAP and HEAVY kernels), scored 64 at a time
 template <bool ON>
 struct SurvLds {};
@@ -256,7 +269,7 @@ struct HeavyLds<true, NWT> {
 };
 
 template <int NWT, bool GAP, bool HEAVY = false>
-struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY> {
+struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, EndLds<GAP && HEAVY> {
     static constexpr int NW = NWT;
     static constexpr int MAXPOS = NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
@@ -1998,6 +2011,15 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                 P.vs = (uint32_t)bits64<NWT / 2>(L.valp[e_chain], ps);
                 P.pad = 0;
                 L.entp[lane] = P;
+                if constexpr (HEAVY) {  // window bit b of a window that starts at read position w0 is read base w0 + b
+                    const int ge = (int)cx.gap_edge, len = (int)rc.len;
+                    SeedEndMask X;
+                    X.fl = low_mask64(ge - pl) & ~low_mask64(-pl);
+                    X.el = low_mask64(len - pl) & ~low_mask64(len - ge - pl);
+                    X.fs = (uint32_t)(low_mask64(ge - ps) & ~low_mask64(-ps));
+                    X.es = (uint32_t)(low_mask64(len - ps) & ~low_mask64(len - ge - ps));
+                    L.entx[lane] = X;
+                }
             }
         }
         wave_sync();
@@ -2058,18 +2080,26 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                         const uint32_t pre_mm = bsel(bm, popc64(D0l), (uint32_t)__popc(D0s));
                         bool gk = false;
                         // (the lanes of a chunk mostly share one seed, hence one window geometry: where the prefix test fails it fails for the whole wave)
-                        if (st.thr >= 2 && pre_mm < st.thr - 1)
+                        if (st.thr >= 2 && pre_mm < st.thr - 1) {
+                            // HEAVY: among the read's first gap_edge bases a mismatch at the candidate's start counts whatever the shifted start says,
+                            // among its last gap_edge bases one at the shifted start (SeedEndMask): D0 & (Ds | F) | Ds & E instead of D0 & Ds
+                            [[maybe_unused]] uint64_t El = 0, F0l = 0;
+                            [[maybe_unused]] uint32_t Es = 0, F0s = 0;
+                            if constexpr (HEAVY) { const SeedEndMask X = L.entx[eif]; El = X.el; Es = X.es; F0l = D0l & X.fl; F0s = D0s & X.fs; }
 #pragma unroll
-                        for (uint32_t tg = 1; tg <= BASAL_MAXGAPS; tg++) {  // tt = 2 tg - 1 (shift -tg), then tt = 2 tg (shift +tg); wave-uniform conditions
-                            if (tg <= cx.gap && st.thr >= 1 + tg) {
-                                // shift -t: read base i against window base i - t
-                                const uint64_t Dm = plane_mismatch(Lhi << tg, Llo << tg, P.ml) & (~0ULL << tg);
-                                const uint32_t dm = plane_mismatch(Shi << tg, Slo << tg, P.ms) & (~0u << tg);
-                                gk |= popc64(D0l & Dm) + (uint32_t)__popc(D0s & dm) <= st.thr - 1;
-                                // shift +t
-                                const uint64_t Dp = plane_mismatch(Lhi >> tg, Llo >> tg, P.ml) & (~0ULL >> tg);
-                                const uint32_t dp = plane_mismatch(Shi >> tg, Slo >> tg, P.ms) & (~0u >> tg);
-                                gk |= popc64(D0l & Dp) + (uint32_t)__popc(D0s & dp) <= st.thr - 1 - tg;
+                            for (uint32_t tg = 1; tg <= BASAL_MAXGAPS; tg++) {  // tt = 2 tg - 1 (shift -tg), then tt = 2 tg (shift +tg); wave-uniform conditions
+                                if (tg <= cx.gap && st.thr >= 1 + tg) {
+                                    // shift -t: read base i against window base i - t
+                                    const uint64_t Dm = plane_mismatch(Lhi << tg, Llo << tg, P.ml) & (~0ULL << tg);
+                                    const uint32_t dm = plane_mismatch(Shi << tg, Slo << tg, P.ms) & (~0u << tg);
+                                    if constexpr (HEAVY) gk |= popc64((Dm & (D0l | El)) | F0l) + (uint32_t)__popc((dm & (D0s | Es)) | F0s) <= st.thr - 1;
+                                    else gk |= popc64(D0l & Dm) + (uint32_t)__popc(D0s & dm) <= st.thr - 1;
+                                    // shift +t
+                                    const uint64_t Dp = plane_mismatch(Lhi >> tg, Llo >> tg, P.ml) & (~0ULL >> tg);
+                                    const uint32_t dp = plane_mismatch(Shi >> tg, Slo >> tg, P.ms) & (~0u >> tg);
+                                    if constexpr (HEAVY) gk |= popc64((Dp & (D0l | El)) | F0l) + (uint32_t)__popc((dp & (D0s | Es)) | F0s) <= st.thr - 1 - tg;
+                                    else gk |= popc64(D0l & Dp) + (uint32_t)__popc(D0s & dp) <= st.thr - 1 - tg;
+                                }
                             }
                         }
                         keep = al || gk;
