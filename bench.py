@@ -584,7 +584,12 @@ def main():
         t = json.load(open(tj))
         plain = args.read_len == 100 and not adhoc and args.genome_scale == 1.0
         key = None if headline else ({"2": "uniform", "4": "config4", "5": "config5", "5p": "config5p"}.get(args.config) if (plain and args.genome == "uniform") else
-                                     {"4": "config4_realistic", "5p": "config5p_realistic"}.get(args.config, "-") if (plain and args.genome == "realistic") else "-")
+                                     {"4": "config4_realistic", "5p": "config5p_realistic", "5": "config5_realistic"}.get(args.config, "-") if (plain and args.genome == "realistic") else "-")
+        if args.read_len == 150 and args.genome_scale == 1.0:  # the 256-base kernels' committed passes
+            if not adhoc and args.config == "2" and args.genome == "realistic":
+                key = "150bp_realistic"
+            elif args.config == "2" and args.rule == "C:T" and args.gap == 2 and args.genome == "uniform":
+                key = "150bp_g2_uniform"
         t = t if key is None else t.get("other_workloads", {}).get(key)
         if t:
             roof["traffic"] = t["hbm_bytes_per_read"] * args.batch
@@ -642,6 +647,19 @@ def main():
         if ref_cpu is not None:  # the reference itself is the baseline; the port on the exact workload stays next to it
             out["config"]["cpu_port"] = cpu
             cpu = ref_cpu
+            # the like-for-like figure -- the same binary on the bench genome itself at -s 16 -- takes a quarter of an hour (tools/ref_like_for_like.py)
+            # and is a committed measurement, cited here
+            lj = os.path.join(ROOT, "profiles", "r04_ref_like_for_like.json")
+            if headline and os.path.exists(lj):
+                try:
+                    l4l = json.load(open(lj))
+                    out["config"]["cpu_like_for_like"] = {"value": l4l["reference_mreads_per_s"], "unit": "Mreads/s", "cores": l4l["threads"], "kind": "reference",
+                                                          "sample": l4l["workload"] + "; align time %.2f s = wall %.1f s minus %.1f s of load + index build; SAM identical to the GPU command line's on all %d reads "
+                                                                    "(profiles/r04_ref_like_for_like.json)" % (l4l["reference_align_s"], l4l["reference_full_s"], l4l["reference_load_and_index_s"], l4l["sam_records"])}
+                    cpu["sample"] += "; like for like (the bench genome itself, 3.09 Gbp at -s 16, tools/ref_like_for_like.py): %.4f Mreads/s on %d cores (config.cpu_like_for_like)" % (
+                        l4l["reference_mreads_per_s"], l4l["threads"])
+                except Exception as e:
+                    log("like-for-like record unreadable: %r" % (e,))
     out["cpu_baseline"] = cpu
     # The default line also carries rounds 1-2's headline workload, the uniform stand-in genome, measured by the same script in a child process
     # (its own genome, index and oracle-checked sample; this process's core stays resident meanwhile: 288 GB hold both).
