@@ -182,8 +182,8 @@ __device__ __forceinline__ void plane_window3(const uint64_t (*q)[NWT + 1], int 
 __shared__ uint16_t s_prof[16][16];
 // the contig table of references with at most 64 contigs (int2hit then needs no memory access)
 __shared__ uint32_t s_anchor[64], s_rcoff[64], s_csize[64];
-// ceil(2^16 / d) for d = 1..16: x / d == (x * s_rcp[d]) >> 16 for x < 4096
-__shared__ uint32_t s_rcp[17];
+// ceil(2^16 / d) for d = 1..32: x / d == (x * s_rcp[d]) >> 16 for x < 2048
+__shared__ uint32_t s_rcp[33];
 
 // GAP kernels: what the stream filter needs of the read opposite one seed's flanks, as bit planes (bit i = window base i, LSB first).
 // ml/ms[X]: the read base there mismatches reference letter X (zero outside the read; N's compare as their code, as in MismatchPattern0/1);
@@ -268,15 +268,18 @@ struct HeavyLds<true, NWT> {
     uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
 
-template <int NWT, bool GAP, bool HEAVY = false>
+// PE (the paired-end instantiations of the standard kernels): a mate runs every mode, so up to eight modes' seeds are set up and streamed as ONE
+// group -- 64 seed entries instead of 32 -- and the log remembers where its records were found (HitState::g)
+template <int NWT, bool GAP, bool HEAVY = false, bool PE = false>
 struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, EndLds<GAP && HEAVY> {
     static constexpr int NW = NWT;
+    static constexpr bool PEK = PE;
     static constexpr int MAXPOS = NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
     uint32_t seed[2][MAXPOS];   // XT hash; bit 31: seed window contains a non-ACGT base
     uint32_t cnt[2][MAXPOS];    // index2[seed].n[0]
     union {
-        SeedEntT<GAP> ent[32];  // the current mode's seeds
+        SeedEntT<GAP> ent[PE ? 64 : 32];  // the current mode's seeds (PE: of up to eight modes)
         uint32_t cs[16][16];  // before the first mode: CountSeeds(n, start) of the chain being ordered
     };
     static constexpr bool GAPK = GAP;
@@ -836,6 +839,8 @@ struct HitState {
     uint32_t nlog;    // records in the log
     uint32_t d0, d1, d2, d3;  // per lane: the four words of log record `lane`
     uint32_t bloom;           // per lane: 32 bits of a 2048-bit Bloom filter over the keys of records 64.. (the ones in memory)
+    uint32_t g;               // per lane (PE kernels): the GLOBAL coordinate record `lane` was found at -- a mate of a pair runs every mode, and every mode finds
+                              // the read's loci again: a candidate at a coordinate the log already holds is dropped before it is scored (process_read)
 };
 
 // the two filter positions of a key (wave-uniform)
@@ -939,7 +944,7 @@ __device__ uint32_t add_hit(const DevCtx &cx, LDS &L, HitState &st, basal_hit *l
         u.h.loc = l; u.h.chr = chr; u.h.gap_size = (int8_t)gap_size; u.h.strand = (uint8_t)(((strand << 1) | chain) & 3);
         u.h.gap_pos = (uint16_t)gp; u.h.level = (uint8_t)w; u.h.chain = (uint8_t)chain; u.h.mode = (uint8_t)mode; u.h.pad = 0;
         if (n < 64) {
-            if ((uint32_t)lane == n) { st.d0 = u.w[0]; st.d1 = u.w[1]; st.d2 = u.w[2]; st.d3 = u.w[3]; }
+            if ((uint32_t)lane == n) { st.d0 = u.w[0]; st.d1 = u.w[1]; st.d2 = u.w[2]; st.d3 = u.w[3]; if constexpr (LDS::PEK) st.g = loc; }
         } else {
             if (lane0(lane)) log[n] = u.h;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the other lanes read the log back later
@@ -1005,8 +1010,8 @@ __device__ __forceinline__ ChunkLoads issue_chunk(const DevCtx &cx, const LDS &L
         if (jj >= e_m) jj -= e_m;
         const uint32_t x = e_off + jj;  // inside locs[] (the mode's set-up checked off + m per seed); kmer_off is 32-bit, so list positions are too
         // (the stream is read once: non-temporal loads in the non-GAP kernels, +1 % there; the GAP kernels lost 1.5 % with them)
-        if (BOTH) { c.loc_raw = cx.locs[x]; c.f = cx.flank_a[x]; c.fb = cx.flank_a[flank_b_off + x]; c.f2 = cx.flank_a[(2ULL + (e_hcs >> 17)) * flank_b_off + x]; }
-        else { c.loc_raw = __builtin_nontemporal_load(&cx.locs[x]); c.f = __builtin_nontemporal_load(&cx.flank_a[(unsigned long long)x + ((e_hcs >> 17) ? flank_b_off : 0ULL)]); }
+        if (BOTH) { c.loc_raw = cx.locs[x]; c.f = cx.flank_a[x]; c.fb = cx.flank_a[flank_b_off + x]; c.f2 = cx.flank_a[(2ULL + ((e_hcs >> 17) & 1u)) * flank_b_off + x]; }
+        else { c.loc_raw = __builtin_nontemporal_load(&cx.locs[x]); c.f = __builtin_nontemporal_load(&cx.flank_a[(unsigned long long)x + (((e_hcs >> 17) & 1u) ? flank_b_off : 0ULL)]); }
         c.ei = ei;
         c.jj = jj;
     }
@@ -1883,10 +1888,11 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
 }
 
 // ---- one read ----------------------------------------------------------------------------------
-template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
-__device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
+template <int NWT, bool NEWRULE, bool GAP, bool HEAVY, bool PE>
+__device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY, PE> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
                              const uint32_t *pre, int pre_c, int lane PH_PARAM) {
-    using LDS = WaveLds<NWT, GAP, HEAVY>;
+    using LDS = WaveLds<NWT, GAP, HEAVY, PE>;
+    static_assert(!PE || (!GAP && !HEAVY), "the paired-end instantiations are the standard kernels'");
     const bool allmodes = (rd.readset & BASAL_READ_ALLMODES) != 0;  // a PE mate: PairAlign::RunAlign drives the modes
     rd.readset &= 0x7f;
     basal_result res;
@@ -1948,18 +1954,34 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
     st.nlog = 0;
     st.d0 = st.d1 = st.d2 = st.d3 = 0;
     st.bloom = 0;
+    st.g = 0;
     const uint32_t rnd = myrand(rc.index, cx.randseed);
-    const uint32_t nent = rfl(2 * cx.I);
-    const uint32_t ent_c = (uint32_t)lane >= cx.I ? 1u : 0u, ent_i = (uint32_t)lane >= cx.I ? (uint32_t)lane - cx.I : (uint32_t)lane;  // lane < 2I
+    const uint32_t n1 = rfl(2 * cx.I);  // seeds per mode
+    // PE kernels: a mate of a pair runs every mode whatever the earlier ones found (PairAlign::RunAlign drives them, pairs.cpp:164-174), so its modes
+    // are set up and streamed in GROUPS of up to eight (64 seed entries): one set-up pass, one header round trip and a few full chunks where eight
+    // modes took eight of each. The stream of a group is the modes' streams back to back -- the order SnpAlign visits the candidates in -- every
+    // candidate knows its mode (bits 20.. of its seed entry), and a level-0 cap, which ends only the SnpAlign call it happens in, restarts the
+    // grouping at the mode behind it. Everything else runs one mode at a time, as before.
+    const uint32_t ent_mo = PE ? ((uint32_t)lane * s_rcp[n1]) >> 16 : 0u, ent_w = (uint32_t)lane - ent_mo * n1;  // lane -> (mode within the group, seed of the mode)
+    const uint32_t ent_c = ent_w >= cx.I ? 1u : 0u, ent_i = ent_w >= cx.I ? ent_w - cx.I : ent_w;
 
     bool done = false;
     for (uint32_t mode = 0; mode < rc.nseg && !done; mode++) {
+        uint32_t G = 1;
+        if constexpr (PE) {
+            if (allmodes) {
+                const uint32_t gmax = n1 <= 8 ? 8u : 64u / n1;
+                G = rc.nseg - mode < gmax ? rc.nseg - mode : gmax;
+            }
+        }
+        const uint32_t nent = PE ? G * n1 : n1;
+        uint32_t stop_mode = 0xffffffffu;  // PE: the mode a level-0 cap ended
         // the seeds of this mode, chain-major then phase (the order SnpAlign visits them, align.cpp:275-279)
         uint32_t e_m = 0, e_off = 0, e_nfwd = 0, e_h = 0, e_jj0 = 0, e_chain = 0;
         if ((uint32_t)lane < nent) {
             const uint32_t c = ent_c, i = ent_i;
             if (rc.on(c)) {
-                uint32_t seg = L.order[c][mode];
+                uint32_t seg = L.order[c][(mode + ent_mo) & 15];
                 uint32_t pos = s_prof[seg & 15][i] + L.start_arr[c][seg & 15] - i;
                 pos = (uint32_t)guard_idx(cx, G_LDSPOS, pos, LDS::MAXPOS, r);
                 uint32_t sd = L.seed[c][pos] & 0x7fffffffu, m = L.cnt[c][pos];
@@ -1977,7 +1999,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
         uint32_t inc = e_m;  // inclusive prefix sum over lanes 0..nent-1
         if (nent <= 16) inc = row16_scan_add(inc);
         else
-            for (int o = 1; o < 32; o <<= 1) {
+            for (int o = 1; o < (PE ? 64 : 32); o <<= 1) {
                 uint32_t v = __shfl_up(inc, o);
                 if (lane >= o) inc += v;
             }
@@ -1993,7 +2015,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
             // the list must lie inside locs[]: checked here, once per seed, so that the stream's chunks need not check every position
             if ((unsigned long long)e_off + e_m > COLD(nlocs)) e_off = guard_u32(cx, G_LOCS, e_off + e_m, 0, r);
             SeedEntT<GAP> e;
-            e.off = e_off; e.m = e_m; e.nfwd = e_nfwd; e.jj0 = e_jj0; e.pre = inc - e_m; e.hcs = e_h | (e_chain << 16) | (side << 17);
+            e.off = e_off; e.m = e_m; e.nfwd = e_nfwd; e.jj0 = e_jj0; e.pre = inc - e_m; e.hcs = e_h | (e_chain << 16) | (side << 17) | (PE ? ent_mo << 20 : 0u);
             if constexpr (HEAVY && !GAP) {  // the flank words of such a core are bit planes: the read's window likewise (win_make)
                 const WinP k = win_make<NEWRULE>(wr, wm, wc);
                 e.fr = (uint64_t)k.rh << 32 | k.rl; e.fm = (uint64_t)k.x << 32 | k.m; e.fc = 0;
@@ -2064,7 +2086,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                         const uint32_t eif = cur.ei;
                         const uint32_t e_hcs = L.ent[eif].hcs, e_nfwd = L.ent[eif].nfwd;
                         const SeedEntPl P = L.entp[eif];
-                        const bool before = (e_hcs >> 17) != 0;
+                        const bool before = ((e_hcs >> 17) & 1u) != 0;
                         const uint32_t lc = cur.loc_raw - (e_hcs & 0xffffu);
                         const uint32_t a_lo = (uint32_t)cur.f, a_hi = (uint32_t)(cur.f >> 32), b_lo = (uint32_t)cur.fb, b_hi = (uint32_t)(cur.fb >> 32);
                         const uint32_t f_lo = (uint32_t)cur.f2, f_hi = (uint32_t)(cur.f2 >> 32);
@@ -2218,11 +2240,34 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                 if (__builtin_expect(T >= cx.win2_min_T, 0)) {
                     if (alive) {
                         const uint32_t h = hcs & 0xffffu;
-                        const uint64_t fo = cx.flank_a[(unsigned long long)guard_u32(cx, G_LOCS, L.ent[ei].off + cur.jj, nlocs_u, r) + ((hcs >> 17) ? 0ULL : flank_b_off)];
+                        const uint64_t fo = cx.flank_a[(unsigned long long)guard_u32(cx, G_LOCS, L.ent[ei].off + cur.jj, nlocs_u, r) + (((hcs >> 17) & 1u) ? 0ULL : flank_b_off)];
                         uint64_t wr, wm, wc;
-                        plane_window3<NWT, NEWRULE>(q, (hcs >> 17) ? (int)(h + cx.K) : (int)h - 32, wr, wm, wc);
+                        plane_window3<NWT, NEWRULE>(q, ((hcs >> 17) & 1u) ? (int)(h + cx.K) : (int)h - 32, wr, wm, wc);
                         alive = lb_first + XM64(cmp_word<NEWRULE>(wr, wc, fo) & wm) <= st.thr;
                     }
+                    if (ballot(alive) == 0) continue;
+                }
+                // A mate of a pair runs every mode (PairAlign::RunAlign drives them, pairs.cpp:164-174), and every mode's seeds find the read's loci again:
+                // 25 filter survivors per mate on the transcriptome stand-in, 24 of them placements the log already holds -- each scored against the
+                // reference and taken through int2hit + AddHit only to be refused as a duplicate (align.h:332-337). A survivor at a global coordinate
+                // (same strand, same chain, ungapped) that one of the 64 records in registers was found at IS such a duplicate: AddHit's key is
+                // (contig, coordinate), a function of exactly that -- dropped here, before it costs anything. (Records 64.. are not looked at: what this
+                // misses goes the ordinary way.)
+                if (PE && allmodes) {
+                    const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
+                    const uint32_t sk = ((strand << 1) | ((hcs >> 16) & 1u)) << 8;  // basal_hit.strand next to gap_size 0, as word 2 of a record holds them
+                    uint64_t known = 0;
+                    for (uint64_t am = ballot(alive); am;) {
+                        const int l = __ffsll((unsigned long long)am) - 1;
+                        const uint32_t kl = rdlane(loc, l), ks = rdlane(sk, l);
+                        // (a group's modes sit side by side in the stream, so the same placement comes several times in ONE chunk too: behind its first
+                        // survivor the others are duplicates of it if it is stored, and refused for the reason it is refused if it is not)
+                        const uint64_t same = ballot(alive && loc == kl && sk == ks);
+                        const bool stored = (ballot(st.g == kl && (st.d2 & 0xffffu) == ks) & in_regs) != 0;
+                        known |= stored ? same : same & ~(1ULL << l);
+                        am &= ~same;
+                    }
+                    if ((known >> lane) & 1) alive = false;
                     if (ballot(alive) == 0) continue;
                 }
                 if (alive) {
@@ -2267,9 +2312,10 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                         ung_pending &= ~bit;
                         uint32_t lmm = rdlane(mm, l);
                         PH(PH_REPLAY);
-                        const uint32_t stop = add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, mode, 0, 0, lane);
+                        const uint32_t lmode = PE ? mode + (rdlane(hcs, l) >> 20) : mode;
+                        const uint32_t stop = add_hit(cx, L, st, log, rc, lloc, lstrand, lchain, lmm, lmode, 0, 0, lane);
                         PH(PH_E1);  // diagnostic build: AddHit's own time, apart from the replay loop around it
-                        if (stop) { done = true; break; }
+                        if (stop) { done = true; stop_mode = lmode; break; }
                         if (st.thr != thr_before) {
                             acc = ballot(mm <= st.thr) & acc;
                             if (GAP) { gap_pending &= ~(bit - 1); recompute = true; break; }
@@ -2306,8 +2352,10 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
         }  // !HEAVY
         // RunAlign: stop once any level <= mode holds a hit (align.cpp:462); `done` = AddHit said stop.
         // For a PE mate the stop only ends this SnpAlign call; the next mode still runs (pairs.cpp:164-174).
-        if (allmodes) done = false;
-        else {
+        if (allmodes) {
+            done = false;
+            if constexpr (PE) mode = stop_mode != 0xffffffffu ? stop_mode : mode + G - 1;  // (the loop's ++ steps behind the group, or behind the mode the cap ended)
+        } else {
             uint32_t any = 0;
             if ((uint32_t)lane <= mode && lane < 16) any = L.nhit[0][lane] | L.nhit[1][lane];
             if (ballot(any != 0)) done = true;
@@ -2395,16 +2443,17 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
 #ifndef BASAL_W8GH
 #define BASAL_W8GH 3
 #endif
-constexpr int waves_per_simd(int nwt, bool gap, bool heavy = false) {
+constexpr int waves_per_simd(int nwt, bool gap, bool heavy = false, bool pe = false) {
     // (HEAVY with longer reads: the survivor list and the Bloom filter leave the LDS room for 4 / 3 blocks per CU)
+    if (pe) return nwt == 4 ? 6 : nwt == 8 ? 4 : 3;  // (64 seed entries: 1.5 KB more LDS per wave)
     if (gap && heavy) return nwt == 4 ? BASAL_W4GH : nwt == 8 ? BASAL_W8GH : 2;
     return nwt == 4 ? (gap ? BASAL_W4G : heavy ? BASAL_W4H : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : heavy ? 4 : BASAL_W8NG) : (gap ? BASAL_W16G : heavy ? 3 : BASAL_W16NG);
 }
 
-template <int NWT, bool NEWRULE, bool GAP, bool HEAVY>
-__global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_kernel(DevCtx cx) {
+template <int NWT, bool NEWRULE, bool GAP, bool HEAVY, bool PE = false>
+__global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY, PE)) void align_kernel(DevCtx cx) {
     __shared__ uint8_t s_tab[5 * 256];
-    __shared__ WaveLds<NWT, GAP, HEAVY> s_w[4];
+    __shared__ WaveLds<NWT, GAP, HEAVY, PE> s_w[4];
 #ifdef BASAL_CHECK_FILTER  // the check build: BASAL_POISON=<byte> fills the block's LDS first -- no result may depend on what LDS held at launch
     if (COLD(lds_poison) >> 8) {
         const uint32_t pat = (COLD(lds_poison) & 0xffu) * 0x01010101u;
@@ -2415,7 +2464,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
 #endif
     for (int i = threadIdx.x; i < 5 * 256; i += 256) s_tab[i] = cx.tables[i];
     s_prof[threadIdx.x >> 4][threadIdx.x & 15] = (uint16_t)profile(threadIdx.x >> 4, threadIdx.x & 15, cx.K, cx.I);
-    if (threadIdx.x >= 1 && threadIdx.x <= 16) s_rcp[threadIdx.x] = (65536u + threadIdx.x - 1) / threadIdx.x;
+    if (threadIdx.x >= 1 && threadIdx.x <= 32) s_rcp[threadIdx.x] = (65536u + threadIdx.x - 1) / threadIdx.x;
     if (threadIdx.x < 64 && threadIdx.x < cx.ncontig && cx.ncontig <= 64) {
         s_anchor[threadIdx.x] = cx.ref_anchor[threadIdx.x];
         s_rcoff[threadIdx.x] = cx.rc_offset[threadIdx.x];
@@ -2427,7 +2476,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    WaveLds<NWT, GAP, HEAVY> &L = s_w[wv];
+    WaveLds<NWT, GAP, HEAVY, PE> &L = s_w[wv];
     if (lane <= NWT) {  // zero the pad words once
         for (int c = 0; c < 2; c++)
             for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
@@ -2502,7 +2551,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
             uint64_t snap[PH_N];
             for (int i = 0; i < PH_N; i++) snap[i] = phc.acc[i];
 #endif
-            process_read<NWT, NEWRULE, GAP, HEAVY>(cx, L, s_tab, log, r, w - base, rd, pre, pc, lane PH_ARG);
+            process_read<NWT, NEWRULE, GAP, HEAVY, PE>(cx, L, s_tab, log, r, w - base, rd, pre, pc, lane PH_ARG);
 #ifdef BASAL_PHASE_TIMING
             {   // histogram of per-read wave-clocks by power of two (diagnostic build)
                 const uint64_t dtc = __builtin_readcyclecounter() - t_read0;
@@ -2546,7 +2595,8 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY)) void align_ke
 
 typedef void (*kernel_fn)(DevCtx);
 template <int NWT>
-kernel_fn pick_kernel(bool newrule, bool gap, bool heavy = false) {
+kernel_fn pick_kernel(bool newrule, bool gap, bool heavy = false, bool pe = false) {
+    if (pe && !gap && !heavy) return newrule ? align_kernel<NWT, true, false, false, true> : align_kernel<NWT, false, false, false, true>;
     if (heavy && gap) return newrule ? align_kernel<NWT, true, true, true> : align_kernel<NWT, false, true, true>;
     if (heavy) return newrule ? align_kernel<NWT, true, false, true> : align_kernel<NWT, false, false, true>;
     if (newrule) return gap ? align_kernel<NWT, true, true, false> : align_kernel<NWT, true, false, false>;
@@ -2757,7 +2807,8 @@ extern "C" int basal_core_launch_info(basal_core_t *c, uint32_t *blocks, uint32_
         int nwt = c->nwt ? c->nwt : 4;
         bool nr = c->p.new_rule != 0, gp = c->p.gap > 0;
         const bool hv = c->heavy;
-        kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv) : nwt == 8 ? pick_kernel<8>(nr, gp, hv) : pick_kernel<16>(nr, gp, hv);
+        const bool pe = c->p.pairend != 0;
+        kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv, pe) : nwt == 8 ? pick_kernel<8>(nr, gp, hv, pe) : pick_kernel<16>(nr, gp, hv, pe);
         hipFuncAttributes at;
         HIP_TRY(hipFuncGetAttributes(&at, (const void *)k));
         *lds_bytes = (uint32_t)at.sharedSizeBytes;
@@ -2831,7 +2882,9 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         cx.heavy_m = e ? (uint32_t)atoi(e) : 128u;
         if (cx.heavy_m < 1) cx.heavy_m = 1;
     }
-    kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv) : nwt == 8 ? pick_kernel<8>(nr, gp, hv) : pick_kernel<16>(nr, gp, hv);
+    // (a paired-end core's standard kernels are the PE instantiations: mode groups for the mates that run every mode)
+    const bool pe = c->p.pairend != 0 && !gp && !hv;
+    kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv, pe) : nwt == 8 ? pick_kernel<8>(nr, gp, hv, pe) : pick_kernel<16>(nr, gp, hv, pe);
     {   // the queue head is zero: the counter block was allocated so, and the last wave of a launch leaves it so (BASAL_HEAD_MEMSET=1: a memset as well)
         static const bool ms = getenv("BASAL_HEAD_MEMSET") && atoi(getenv("BASAL_HEAD_MEMSET")) != 0;
         if (ms) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), s));
@@ -2839,7 +2892,7 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     cx.guard = counter + 1;
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
     const char *env = getenv("BASAL_BLOCKS_PER_CU");
-    uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, hv);
+    uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, hv, pe);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;

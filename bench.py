@@ -185,6 +185,7 @@ def bench_pairs(args):
         pms.append(float(L.basal_core_last_pair_ms(core.h)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    bc._check(L.basal_core_sync_check(core.h), "align kernels")  # the kernels' bounds ledger (and, in the diagnostic build, the phase clocks)
     paired = st[0] / (npairs * args.steps)
     out = {"metric": "Mpairs/s aligned and paired (150 bp PE, -M A:G, transcriptome stand-in), host buffers to host records", "value": npairs * args.steps / dt / 1e6, "unit": "Mpairs/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
