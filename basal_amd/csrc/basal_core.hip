@@ -212,6 +212,9 @@ __device__ __forceinline__ uint64_t bits64(const uint64_t *pl, int start) {
 #ifndef WORK_CHUNK
 #define WORK_CHUNK 8  // reads a wave takes from the queue per atomic
 #endif
+#ifndef BASAL_PE_ENT
+#define BASAL_PE_ENT 64  // PE kernels: seed entries of a mode group (64: eight modes at -I 4)
+#endif
 #ifndef BLOOM_WORDS
 #define BLOOM_WORDS 256  // 8 192 bits: 123.0 -> 119.0 ms per 10 M reads against 4 096 (fewer look-ups of the memory log for reads with a thousand hits); 16 384 would cost the fifth block per CU
 #endif
@@ -279,7 +282,7 @@ struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, 
     uint32_t seed[2][MAXPOS];   // XT hash; bit 31: seed window contains a non-ACGT base
     uint32_t cnt[2][MAXPOS];    // index2[seed].n[0]
     union {
-        SeedEntT<GAP> ent[PE ? 64 : 32];  // the current mode's seeds (PE: of up to eight modes)
+        SeedEntT<GAP> ent[PE ? BASAL_PE_ENT : 32];  // the current mode's seeds (PE: of up to eight modes)
         uint32_t cs[16][16];  // before the first mode: CountSeeds(n, start) of the chain being ordered
     };
     static constexpr bool GAPK = GAP;
@@ -289,6 +292,7 @@ struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, 
     uint32_t nhit[2][16];  // x_cur_n_hit[chain][level]
     uint8_t start_arr[2][16];
     uint8_t order[2][16];
+    uint32_t stg_n, stg_mask;  // hit-stream records staged for the reads of this chunk (stream_flush), and which of the chunk's reads they belong to
 };
 
 // LDS written by one lane and read by the others of the SAME wave: LDS ops of a wave execute in
@@ -1887,6 +1891,32 @@ __device__ bool heavy_mode(const DevCtx &cx, LDS &L, HitState &st, basal_hit *lo
     return stop;
 }
 
+// ---- the hit stream (-r 2: the best level's hits; paired-end: every mate's whole log) ---------------------------------------------------
+// Its records are handed out by ONE counter, and a single memory word takes about 80 M atomic adds per second on this chip -- a paired-end batch,
+// one log per mate, ran at exactly that rate whatever the kernel did (config 3: 25.5 ms per 2 M mates before and after its instruction count
+// fell by a third). So a read's records (up to 64) are first STAGED in the wave's own scratch -- the first 64 records of its hit-log area, which
+// live in registers and are never stored there -- and a chunk of reads takes its place in the stream with one atomic add: the same exact total,
+// the same overflow rule per read, an eighth of the atomics. Logs of more than 64 records go straight to the stream as before.
+template <class LDS>
+__device__ __forceinline__ void stream_flush(const DevCtx &cx, LDS &L, basal_hit *log, int lane) {
+    const uint32_t total = rfl(L.stg_n);
+    if (!total) return;
+    unsigned long long first = 0;
+    if (lane0(lane)) first = atomicAdd(COLDP(unsigned long long, stream_used), (unsigned long long)total);
+    first = ((unsigned long long)rfl((uint32_t)(first >> 32)) << 32) | rfl((uint32_t)first);
+    const unsigned long long cap = COLD(stream_cap);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (the staged records were stored by other lanes of this wave)
+    if ((uint32_t)lane < total && first + (uint32_t)lane < cap) COLDP(basal_hit, stream)[first + (uint32_t)lane] = log[lane];
+    const uint32_t mask = rfl(L.stg_mask);
+    if (lane < WORK_CHUNK && ((mask >> lane) & 1u)) {
+        const uint32_t rel = L.res[lane].stream_first;
+        L.res[lane].stream_first = (uint32_t)(first + rel);
+        if (first + rel + L.res[lane].stream_n > cap) L.res[lane].status = BASAL_READ_OVERFLOW;
+    }
+    if (lane0(lane)) { L.stg_n = 0; L.stg_mask = 0; }
+    wave_sync();
+}
+
 // ---- one read ----------------------------------------------------------------------------------
 template <int NWT, bool NEWRULE, bool GAP, bool HEAVY, bool PE>
 __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP, HEAVY, PE> &L, const uint8_t *tab, basal_hit *log, uint32_t r, uint32_t chunk_slot, basal_read rd,
@@ -1970,7 +2000,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
         uint32_t G = 1;
         if constexpr (PE) {
             if (allmodes) {
-                const uint32_t gmax = n1 <= 8 ? 8u : 64u / n1;
+                const uint32_t gmax = n1 * 8u <= (uint32_t)BASAL_PE_ENT ? 8u : (uint32_t)BASAL_PE_ENT / n1;
                 G = rc.nseg - mode < gmax ? rc.nseg - mode : gmax;
             }
         }
@@ -2376,7 +2406,50 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
         uint32_t j = sum == 1 ? 0 : rnd % sum;
         uint32_t idx = j < nh ? find_kth(st, log, ii, 0, j, lane) : find_kth(st, log, ii, 1, j - nh, lane);
         if (idx != 0xffffffffu) res.best = log_record(st, log, idx);
+        if constexpr (PE) {
         if (COLD(stream_mode) == BASAL_STREAM_BEST || COLD(stream_mode) == BASAL_STREAM_ALL) {
+            uint32_t need = COLD(stream_mode) == BASAL_STREAM_ALL ? st.nlog : sum;
+            res.stream_n = need;
+            // (PE kernels only -- every mate has a log there; the other instantiations keep one atomic per read with hits and their register budget)
+            const bool staged = need <= 64;  // (stream_flush gives the chunk's staged records their place in the stream)
+            unsigned long long first = 0;
+            if (staged) {
+                if (need > 64 - rfl(L.stg_n)) stream_flush(cx, L, log, lane);  // make room: the reads staged so far take their place now
+                first = rfl(L.stg_n);
+            } else {
+                if (lane0(lane)) first = atomicAdd(COLDP(unsigned long long, stream_used), (unsigned long long)need);
+                first = ((unsigned long long)rfl((uint32_t)(first >> 32)) << 32) | rfl((uint32_t)first);
+                if (first + need > COLD(stream_cap)) res.status = BASAL_READ_OVERFLOW;
+            }
+            // (two stores under a wave-uniform branch: a select between the two pointers would compile to flat stores)
+            auto put = [&](unsigned long long at, const basal_hit &h) { if (staged) log[at] = h; else COLDP(basal_hit, stream)[at] = h; };
+            res.stream_first = (uint32_t)first;
+            if (res.status == BASAL_READ_OVERFLOW) {
+            } else if (COLD(stream_mode) == BASAL_STREAM_ALL) {
+                for (uint32_t base = 0; base < st.nlog; base += 64)
+                    if (base + lane < st.nlog) put(first + base + lane, log_lane_record(st, log, base, lane));
+            } else {
+                uint32_t outp = 0;
+                for (uint32_t c = 0; c < 2; c++)
+                    for (uint32_t base = 0; base < st.nlog; base += 64) {
+                        bool m = false;
+                        basal_hit h;
+                        if (base + lane < st.nlog) {
+                            h = log_lane_record(st, log, base, lane);
+                            m = h.level == ii && h.chain == c;
+                        }
+                        uint64_t b = ballot(m);
+                        if (m) put(first + outp + (uint32_t)__popcll(b & ((1ULL << lane) - 1)), h);
+                        outp += (uint32_t)__popcll(b);
+                    }
+            }
+            if (staged) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // other lanes read the staged records back (stream_flush)
+                if (lane0(lane)) { L.stg_n = (uint32_t)first + need; L.stg_mask |= 1u << chunk_slot; }
+                wave_sync();
+            }
+        }
+        } else if (COLD(stream_mode) == BASAL_STREAM_BEST || COLD(stream_mode) == BASAL_STREAM_ALL) {
             uint32_t need = COLD(stream_mode) == BASAL_STREAM_ALL ? st.nlog : sum;
             unsigned long long first = 0;
             if (lane0(lane)) first = atomicAdd(COLDP(unsigned long long, stream_used), (unsigned long long)need);
@@ -2445,7 +2518,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
 #endif
 constexpr int waves_per_simd(int nwt, bool gap, bool heavy = false, bool pe = false) {
     // (HEAVY with longer reads: the survivor list and the Bloom filter leave the LDS room for 4 / 3 blocks per CU)
-    if (pe) return nwt == 4 ? 6 : nwt == 8 ? 4 : 3;  // (64 seed entries: 1.5 KB more LDS per wave)
+    if (pe) return BASAL_PE_ENT > 32 ? (nwt == 4 ? 6 : nwt == 8 ? 4 : 3) : (nwt == 4 ? BASAL_W4NG : nwt == 8 ? BASAL_W8NG : BASAL_W16NG);  // (64 seed entries: 1.5 KB more LDS per wave)
     if (gap && heavy) return nwt == 4 ? BASAL_W4GH : nwt == 8 ? BASAL_W8GH : 2;
     return nwt == 4 ? (gap ? BASAL_W4G : heavy ? BASAL_W4H : BASAL_W4NG) : nwt == 8 ? (gap ? BASAL_W8G : heavy ? 4 : BASAL_W8NG) : (gap ? BASAL_W16G : heavy ? 3 : BASAL_W16NG);
 }
@@ -2477,6 +2550,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY, PE)) void alig
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     WaveLds<NWT, GAP, HEAVY, PE> &L = s_w[wv];
+    if (lane0(lane)) L.stg_n = L.stg_mask = 0;
     if (lane <= NWT) {  // zero the pad words once
         for (int c = 0; c < 2; c++)
             for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
@@ -2565,6 +2639,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY, PE)) void alig
         // the chunk's results leave in one coalesced store (a store per read would have every read wait for the
         // previous read's write acknowledgement at its first memory wait)
         wave_sync();
+        if constexpr (PE) if (COLD(stream_mode) != BASAL_STREAM_NONE) stream_flush(cx, L, log, lane);  // the chunk's staged hit-stream records take their place (and the results learn it)
         static_assert(WORK_CHUNK * sizeof(basal_result) == 64 * sizeof(uint32_t), "one dword per lane");
         if ((uint32_t)lane < (end - base) * (uint32_t)(sizeof(basal_result) / 4)) {
             if (!LISTED) ((uint32_t *)(COLDP(basal_result, results) + base))[lane] = ((const uint32_t *)L.res)[lane];
@@ -2649,7 +2724,7 @@ extern "C" int basal_core_create(const basal_params *p, int device, basal_core_t
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     c->total_kmers = pow3(p->seed_size);
-    c->scratch_per_wave = 16 * p->max_num_hits;
+    c->scratch_per_wave = 16 * p->max_num_hits < 64 ? 64 : 16 * p->max_num_hits;  // (at least 64: the first 64 records of a wave's area stage its hit-stream records, stream_flush)
     *out = c;
     return BASAL_OK;
 }

@@ -48,7 +48,7 @@ def main():
     # a device function that was NOT inlined into its kernel (it then takes LDS and global pointers as generic ones: flat loads, a stack of
     # several hundred bytes per lane) -- every function of this file is meant to end up inside an align_kernel instantiation or a small kernel
     for l in lines:
-        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+(process_read|heavy_mode|heavy_flush|bulk_add|bulk_add2|gap_flush|gap_search|dups_among|dups_stored|prep_read|reorder_seed|add_hit|gap_align)\w*):", l)
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+(process_read|heavy_mode|heavy_flush|bulk_add|bulk_add2|gap_flush|gap_search|dups_among|dups_stored|stream_flush|prep_read|reorder_seed|add_hit|gap_align)\w*):", l)
         if m:
             print("not inlined: %s" % m.group(1)[:100])
             bad += 1
