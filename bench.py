@@ -195,7 +195,7 @@ def bench_pairs(args):
                       "pairs_per_step": npairs, "mpairs_per_s_host_to_host": npairs * args.steps / dt / 1e6,
                       "mpairs_per_s_kernels": npairs / ((np.mean(kms) + np.mean(pms)) * 1e-3) / 1e6, "align_kernel_ms": float(np.mean(kms)), "pair_kernel_ms": float(np.mean(pms)),
                       "paired_frac": paired},
-           "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "align_kernel<8,false,false> + pair_kernel",
+           "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "align_kernel<8,false,false,false,PE> + pair_kernel",
                         "kernel_ms": float(np.mean(kms) + np.mean(pms))},
            "cpu_baseline": None}
     # ---- parity + algorithmic bytes on a bounded sample, through files: the product's command line and the CPU oracle's on the same FASTA
