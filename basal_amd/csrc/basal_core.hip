@@ -213,8 +213,8 @@ __device__ __forceinline__ uint64_t bits64(const uint64_t *pl, int start) {
 #define WORK_CHUNK 8  // reads a wave takes from the queue per atomic
 #endif
 #ifndef BASAL_PE_ENT
-#define BASAL_PE_ENT 64  // PE kernels: seed entries of a mode group (64: eight modes at -I 4)
-#endif
+#define BASAL_PE_ENT 32  // PE kernels: seed entries of a mode group. 32 = four modes at -I 4 in the LDS the standard kernels have (config 3: 16.4 ms per 1 M pairs);
+#endif                   // 64 = eight modes, 1.5 KB more LDS per wave and a block less per CU (17.4 ms)
 #ifndef BLOOM_WORDS
 #define BLOOM_WORDS 256  // 8 192 bits: 123.0 -> 119.0 ms per 10 M reads against 4 096 (fewer look-ups of the memory log for reads with a thousand hits); 16 384 would cost the fifth block per CU
 #endif
@@ -271,8 +271,8 @@ struct HeavyLds<true, NWT> {
     uint32_t bucket[32];  // bulk_add: the lowest lane of each key-hash bucket (with 64 buckets the block's LDS would not fit six times into a CU)
 };
 
-// PE (the paired-end instantiations of the standard kernels): a mate runs every mode, so up to eight modes' seeds are set up and streamed as ONE
-// group -- 64 seed entries instead of 32 -- and the log remembers where its records were found (HitState::g)
+// PE (the paired-end instantiations of the standard kernels): a mate runs every mode, so several modes' seeds (BASAL_PE_ENT entries: four modes at
+// -I 4) are set up and streamed as ONE group, and the log remembers where its records were found (HitState::g)
 template <int NWT, bool GAP, bool HEAVY = false, bool PE = false>
 struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, EndLds<GAP && HEAVY> {
     static constexpr int NW = NWT;
@@ -1988,18 +1988,19 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
     const uint32_t rnd = myrand(rc.index, cx.randseed);
     const uint32_t n1 = rfl(2 * cx.I);  // seeds per mode
     // PE kernels: a mate of a pair runs every mode whatever the earlier ones found (PairAlign::RunAlign drives them, pairs.cpp:164-174), so its modes
-    // are set up and streamed in GROUPS of up to eight (64 seed entries): one set-up pass, one header round trip and a few full chunks where eight
-    // modes took eight of each. The stream of a group is the modes' streams back to back -- the order SnpAlign visits the candidates in -- every
+    // are set up and streamed in GROUPS (BASAL_PE_ENT seed entries: four modes at -I 4): one set-up pass, one header round trip and a few full chunks
+    // where four modes took four of each. The stream of a group is the modes' streams back to back -- the order SnpAlign visits the candidates in -- every
     // candidate knows its mode (bits 20.. of its seed entry), and a level-0 cap, which ends only the SnpAlign call it happens in, restarts the
     // grouping at the mode behind it. Everything else runs one mode at a time, as before.
     const uint32_t ent_mo = PE ? ((uint32_t)lane * s_rcp[n1]) >> 16 : 0u, ent_w = (uint32_t)lane - ent_mo * n1;  // lane -> (mode within the group, seed of the mode)
     const uint32_t ent_c = ent_w >= cx.I ? 1u : 0u, ent_i = ent_w >= cx.I ? ent_w - cx.I : ent_w;
 
     bool done = false;
+    bool capped = false;  // PE: a level-0 cap has ended one of this read's modes (a read from a repeat family: its later modes run one at a time)
     for (uint32_t mode = 0; mode < rc.nseg && !done; mode++) {
         uint32_t G = 1;
         if constexpr (PE) {
-            if (allmodes) {
+            if (allmodes && !capped) {
                 const uint32_t gmax = n1 * 8u <= (uint32_t)BASAL_PE_ENT ? 8u : (uint32_t)BASAL_PE_ENT / n1;
                 G = rc.nseg - mode < gmax ? rc.nseg - mode : gmax;
             }
@@ -2283,7 +2284,8 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                 // (same strand, same chain, ungapped) that one of the 64 records in registers was found at IS such a duplicate: AddHit's key is
                 // (contig, coordinate), a function of exactly that -- dropped here, before it costs anything. (Records 64.. are not looked at: what this
                 // misses goes the ordinary way.)
-                if (PE && allmodes) {
+                // (chunks with a handful of survivors -- the unique read's case; a chunk full of a repeat family's copies goes the ordinary way)
+                if (PE && allmodes && __popcll(ballot(alive)) <= 8) {
                     const uint64_t in_regs = st.nlog >= 64 ? ~0ULL : (1ULL << st.nlog) - 1;
                     const uint32_t sk = ((strand << 1) | ((hcs >> 16) & 1u)) << 8;  // basal_hit.strand next to gap_size 0, as word 2 of a record holds them
                     uint64_t known = 0;
@@ -2384,7 +2386,10 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
         // For a PE mate the stop only ends this SnpAlign call; the next mode still runs (pairs.cpp:164-174).
         if (allmodes) {
             done = false;
-            if constexpr (PE) mode = stop_mode != 0xffffffffu ? stop_mode : mode + G - 1;  // (the loop's ++ steps behind the group, or behind the mode the cap ended)
+            if constexpr (PE) {  // (the loop's ++ steps behind the group, or behind the mode the cap ended)
+                capped |= stop_mode != 0xffffffffu;
+                mode = stop_mode != 0xffffffffu ? stop_mode : mode + G - 1;
+            }
         } else {
             uint32_t any = 0;
             if ((uint32_t)lane <= mode && lane < 16) any = L.nhit[0][lane] | L.nhit[1][lane];
@@ -2958,7 +2963,8 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         if (cx.heavy_m < 1) cx.heavy_m = 1;
     }
     // (a paired-end core's standard kernels are the PE instantiations: mode groups for the mates that run every mode)
-    const bool pe = c->p.pairend != 0 && !gp && !hv;
+    static const bool pe_off = getenv("BASAL_PE") && atoi(getenv("BASAL_PE")) == 0;  // (BASAL_PE=0: the standard kernels for paired-end cores too; A/B and tests)
+    const bool pe = c->p.pairend != 0 && !gp && !hv && !pe_off;
     kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv, pe) : nwt == 8 ? pick_kernel<8>(nr, gp, hv, pe) : pick_kernel<16>(nr, gp, hv, pe);
     {   // the queue head is zero: the counter block was allocated so, and the last wave of a launch leaves it so (BASAL_HEAD_MEMSET=1: a memset as well)
         static const bool ms = getenv("BASAL_HEAD_MEMSET") && atoi(getenv("BASAL_HEAD_MEMSET")) != 0;
