@@ -210,6 +210,19 @@ def test_cli_pe_sam_matches_golden(name, tmp_path):
     assert got == exp
 
 
+@pytest.mark.parametrize("name", H.PE)
+def test_cli_pe_standard_kernels_match_golden(name, tmp_path):
+    """A paired-end core launches the paired-end instantiations of its standard kernels (a mate's modes in groups, placements the log already holds
+    dropped before they are scored, hit-stream records staged per chunk of reads: DESIGN 8, round 4 item 6) -- every other paired-end test runs
+    through them.  BASAL_PE=0 keeps the standard kernels: the same golden SAMs, i.e. the two families agree record for record."""
+    fa, fq, fq2, _ = H.fixture_paths(name)
+    out = tmp_path / "o.sam"
+    r = subprocess.run([BASAL_BIN, "-a", fq, "-b", fq2, "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "3", "-o", str(out)], capture_output=True, text=True,
+                       env=dict(os.environ, BASAL_PE="0"))
+    assert r.returncode == 0, r.stderr
+    assert "".join(l for l in open(out) if not l.startswith("@PG")) == H.golden_sam(name)
+
+
 @pytest.mark.parametrize("name", ["pe_rep_r2", "pe_dirty_r1"])
 def test_cli_pe_small_batches(name, tmp_path):
     fa, fq, fq2, _ = H.fixture_paths(name)
