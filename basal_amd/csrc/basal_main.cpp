@@ -462,7 +462,7 @@ size_t cut_at_record(const char *buf, size_t n, bool fastq, bool at_eof) {
     return 0;
 }
 
-struct SePlan { bool plain = false; basal_pipe_opts po; };
+struct SePlan { bool plain = false; basal_pipe_opts po; uint64_t light_bytes = 0; uint32_t light_reads = 0; };  // light_*: the batch of an index without long lists
 
 // the input form and the batch geometry (before anything is staged: the pipeline's page-locked buffers are set up meanwhile)
 SePlan plan_se(const Cli &cli) {
@@ -485,7 +485,12 @@ SePlan plan_se(const Cli &cli) {
     po.depth = 3;
     // batches of half a million reads: a batch costs a few tenths of a millisecond of fixed GPU time, while page-locking its
     // buffers costs host time in proportion to their size
-    po.max_reads = cli.batch ? (uint32_t)std::min<size_t>(cli.batch, 16u << 20) : (512u << 10);
+    // The pipe's buffers are sized for 2 Mi reads per batch; how much of that a batch uses is decided when the index is there (run_se): a launch cannot
+    // end before its longest read has, and on a repeat-rich index (over-represented-k-mer cut-off >= 32 768: any real genome) one read in 80 000
+    // runs 14-28 ms -- batches of half a million reads then cost 16 ms each instead of 6 (26 against 45 Mreads/s on the hg38-like stand-in), while on
+    // an index without long lists the smaller batch overlaps the stages better (87 against 80). -Z sets both.
+    const uint32_t light_reads = cli.batch ? (uint32_t)std::min<size_t>(cli.batch, 16u << 20) : (512u << 10);
+    po.max_reads = cli.batch ? light_reads : (2048u << 10);
     // bytes per batch: room for 100-base FASTQ records with short names at max_reads; longer records make batches of fewer reads
     po.max_bytes = std::min<uint64_t>((uint64_t)po.max_reads * 160 + (1u << 20), 0xF0000000ull);
     if (est_bytes < po.max_bytes) {  // a small input: small buffers (page-locking gigabytes takes longer than aligning a few thousand reads)
@@ -499,13 +504,19 @@ SePlan plan_se(const Cli &cli) {
     SePlan pl;
     pl.plain = plain;
     pl.po = po;
+    pl.light_reads = std::min(light_reads, po.max_reads);
+    pl.light_bytes = std::min<uint64_t>(((uint64_t)pl.light_reads * 160 + (1u << 20) + 4095ull) & ~4095ull, po.max_bytes);
     return pl;
 }
 
-void run_se(Cli &cli, basal_pipe_t *pipe, const SePlan &plan, Output &out, SeStats &st, double &t_wait_gpu) {
+void run_se(Cli &cli, basal_pipe_t *pipe, const SePlan &plan, bool long_lists, Output &out, SeStats &st, double &t_wait_gpu) {
     const basal_params &P = cli.P;
     bool plain = plan.plain;
-    const basal_pipe_opts po = plan.po;
+    basal_pipe_opts po = plan.po;
+    if (!long_lists) {  // (an index without long lists: the smaller batch -- see plan_se; the pipe's buffers hold either)
+        po.max_bytes = std::min<uint64_t>(po.max_bytes, plan.light_bytes);
+        po.max_reads = std::min(po.max_reads, plan.light_reads);
+    }
     if (basal_pipe_set_read_range(pipe, cli.read_start - 1, cli.read_end)) die(basal_last_error());
 
     // reader thread -> pipe; the main thread collects and writes. A refused (irregular) text batch restarts the reader in
@@ -1416,6 +1427,10 @@ void run_pe(Cli &cli, Aligner &al, basal_ref_t *R, Output &out, uint32_t pst[9],
 }  // namespace
 
 int main(int argc, char **argv) {
+    // HIP maps streams of one priority onto a few hardware queues (4 by default), and two streams on one queue run in submission order. The batch
+    // pipeline alternates consecutive batches' kernels between two streams so that the end of one align launch (a few waves finishing its longest
+    // reads) overlaps the next batch's kernels: they need queues of their own. Read by the runtime when it starts, i.e. before the first HIP call.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Cli cli;
     basal_params &P = cli.P;
     basal_host_params_defaults(&P);
@@ -1629,7 +1644,7 @@ int main(int argc, char **argv) {
             if (!pipe) die("cannot create the pipeline: " + pipe_err);
             st.t_create = t_pipe;
             t3 = now();
-            run_se(cli, pipe, plan, out, st, t_wait);
+            run_se(cli, pipe, plan, mk >= 32768 && !getenv("BASAL_HEAVY"), out, st, t_wait);
         }
         out.close();
         double t4 = now();

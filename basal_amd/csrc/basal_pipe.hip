@@ -54,6 +54,7 @@ struct Slot {
     int mode = MODE_TEXT;
     uint32_t n_host = 0, max_len = 0;
     uint64_t nbytes = 0;
+    hipStream_t comp = nullptr;  // the kernel stream of the batch this slot holds (one of its GPU's two, by batch number)
     bool out_queued = false;  // the D2H copy of the output has been queued
     bool collecting = false;  // basal_pipe_collect is working on this slot (the submitter leaves it alone)
     uint64_t out_bytes = 0;
@@ -66,6 +67,12 @@ struct PipeDev {
     basal_core *c = nullptr;
     PrepShared sh;
     hipStream_t st_in = nullptr, st_comp = nullptr, st_out = nullptr, st_cnt = nullptr;  // st_cnt: the few bytes of counters per batch (the host sizes the output copy from them; they must not queue behind an output copy)
+    // A second kernel stream: consecutive batches' kernels alternate between the two, so the END of one batch's align launch -- a few waves finishing
+    // its longest reads, 10-25 ms on a repeat-rich index whatever the batch size -- overlaps the next batch's kernels instead of idling the GPU.
+    // What orders the batches is the carry state alone: batch b + 1's prep kernels wait for the event behind batch b's (EV_PREP), as they do across GPUs.
+    // (The two streams must land on different hardware queues to overlap: HIP maps streams of one priority onto few queues -- the `basal` command line
+    // sets GPU_MAX_HW_QUEUES=8 before HIP starts; a host that embeds the library should do the same.)
+    hipStream_t st_comp2 = nullptr;
 };
 
 // A pipe over one GPU, or over several (basal_pipe_create_multi): whole batches fan out over the GPUs, the way the reference's worker
@@ -136,6 +143,7 @@ extern "C" void basal_pipe_destroy(basal_pipe_t *p) {
         for (uint32_t i = 0; i < v.sh.ncarry; i++) hipFree(v.sh.carry[i]);
         if (v.st_in) hipStreamDestroy(v.st_in);
         if (v.st_comp) hipStreamDestroy(v.st_comp);
+        if (v.st_comp2) hipStreamDestroy(v.st_comp2);
         if (v.st_out) hipStreamDestroy(v.st_out);
         if (v.st_cnt) hipStreamDestroy(v.st_cnt);
     }
@@ -251,6 +259,7 @@ extern "C" int basal_pipe_create_multi(basal_core_t *const *cores, int ncores, c
         if (e && strlen(e) == 4) { auto lv = [&](char ch) { return ch == 'h' ? hi : ch == 'l' ? lo : (lo + hi) / 2; }; pin = lv(e[0]); pcomp = lv(e[1]); pout = lv(e[2]); pcnt = lv(e[3]); }
         TRYD(hipStreamCreateWithPriority(&v.st_in, hipStreamNonBlocking, pin));
         TRYD(hipStreamCreateWithPriority(&v.st_comp, hipStreamNonBlocking, pcomp));
+        TRYD(hipStreamCreateWithPriority(&v.st_comp2, hipStreamNonBlocking, pcomp));
         TRYD(hipStreamCreateWithPriority(&v.st_out, hipStreamNonBlocking, pout));
         TRYD(hipStreamCreateWithPriority(&v.st_cnt, hipStreamNonBlocking, pcnt));
     }
@@ -318,7 +327,7 @@ static int queue_align(basal_pipe *p, Slot &s) {
         basal_align_extra ex;
         ex.counter = d.counter;
         ex.scratch = d.scratch;
-        return basal_launch_align(c, d.text, s.nbytes, d.raw, s.n_host, nullptr, 0, s.max_len, BASAL_STREAM_NONE, d.results, nullptr, 0, &d.cnt->stream_used, v.st_comp, &ex);
+        return basal_launch_align(c, d.text, s.nbytes, d.raw, s.n_host, nullptr, 0, s.max_len, BASAL_STREAM_NONE, d.results, nullptr, 0, &d.cnt->stream_used, s.comp, &ex);
     }
     static const uint32_t cls_len[3] = {128, 256, BASAL_MAXREADLEN};
     for (int cl = 0; cl < 3; cl++) {
@@ -329,7 +338,7 @@ static int queue_align(basal_pipe *p, Slot &s) {
         ex.ghost_base = mr;
         ex.counter = d.counter;
         ex.scratch = d.scratch;
-        int rc = basal_launch_align(c, d.text, d.text_cap + 1024, d.desc, mr, d.stales, mr, cls_len[cl], smode, d.results, d.stream, d.stream_cap, &d.cnt->stream_used, v.st_comp, &ex);
+        int rc = basal_launch_align(c, d.text, d.text_cap + 1024, d.desc, mr, d.stales, mr, cls_len[cl], smode, d.results, d.stream, d.stream_cap, &d.cnt->stream_used, s.comp, &ex);
         if (rc) return rc;
     }
     return BASAL_OK;
@@ -340,12 +349,12 @@ static int queue_format(basal_pipe *p, Slot &s) {
     PipeDev &v = p->devs[(size_t)s.dev];
     basal_core *c = v.c;
     SlotDev &d = s.d;
-    if (!(p->o.flags & BASAL_PIPE_PAIRS)) return prep_enqueue_format(c, p->k, d, v.sh, p->o.max_reads, v.st_comp);
+    if (!(p->o.flags & BASAL_PIPE_PAIRS)) return prep_enqueue_format(c, p->k, d, v.sh, p->o.max_reads, s.comp);
     const uint32_t npairs = s.n_host / 2;
-    if (basal_fill_async(&d.cnt->pe[0], sizeof d.cnt->pe, 0, v.st_comp) || basal_fill_async(&d.cnt->pe_recs_used, sizeof d.cnt->pe_recs_used, 0, v.st_comp)) return BASAL_EDEVICE;
-    int rc = basal_pe_enqueue(c, d.desc, d.results, d.stream, d.pe_work, npairs, d.pe_pairs, d.pe_recs, d.pe_recs_cap, &d.cnt->pe_recs_used, d.cnt->pe, v.st_comp);
+    if (basal_fill_async(&d.cnt->pe[0], sizeof d.cnt->pe, 0, s.comp) || basal_fill_async(&d.cnt->pe_recs_used, sizeof d.cnt->pe_recs_used, 0, s.comp)) return BASAL_EDEVICE;
+    int rc = basal_pe_enqueue(c, d.desc, d.results, d.stream, d.pe_work, npairs, d.pe_pairs, d.pe_recs, d.pe_recs_cap, &d.cnt->pe_recs_used, d.cnt->pe, s.comp);
     if (rc) return rc;
-    return prep_enqueue_format_pe(c, p->k, d, v.sh, npairs, p->o.max_reads, v.st_comp);
+    return prep_enqueue_format_pe(c, p->k, d, v.sh, npairs, p->o.max_reads, s.comp);
 }
 
 static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, int format, uint32_t first_index, uint32_t readset, uint32_t max_len,
@@ -395,6 +404,7 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
         src_slot = p->carry_slot[bno % p->ncarry];
     }
     s.batch_no = bno;
+    s.comp = (bno & 1u) && !getenv("BASAL_PIPE_ONE_STREAM") ? v.st_comp2 : v.st_comp;
 #define TRYS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return fail(BASAL_EDEVICE); } } while (0)
 #define TRYR(x) do { int r_ = (x); if (r_) return fail(r_); } while (0)
     // copies in
@@ -404,26 +414,26 @@ static int submit_common(basal_pipe *p, int mode, uint64_t nbytes, uint32_t n, i
     if (mode == MODE_PREPARED && n) TRYS(hipMemcpyAsync(d.raw, s.h_raw, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, v.st_in));
     TRYS(hipEventRecord(s.ev[EV_H2D], v.st_in));
     // kernels (this stream also keeps the batches' carry states in order)
-    TRYS(hipStreamWaitEvent(v.st_comp, s.ev[EV_H2D], 0));
-    TRYS(hipEventRecord(s.ev[EV_COMP0], v.st_comp));
-    if (basal_fill_async(d.cnt, sizeof(BatchCounters), 0, v.st_comp)) return BASAL_EDEVICE;
-    if (mode != MODE_PREPARED && src_dev >= 0 && src_dev != s.dev) {
-        // the state this batch starts from was written on another GPU, by the prep kernels of the batch before: fetch it behind them
+    TRYS(hipStreamWaitEvent(s.comp, s.ev[EV_H2D], 0));
+    TRYS(hipEventRecord(s.ev[EV_COMP0], s.comp));
+    if (basal_fill_async(d.cnt, sizeof(BatchCounters), 0, s.comp)) return BASAL_EDEVICE;
+    // the state this batch starts from was written by the prep kernels of the batch before, on the other kernel stream or on another GPU: behind them
+    if (mode != MODE_PREPARED && src_slot >= 0 && src_slot != si) TRYS(hipStreamWaitEvent(s.comp, p->slots[(size_t)src_slot].ev[EV_PREP], 0));
+    if (mode != MODE_PREPARED && src_dev >= 0 && src_dev != s.dev) {  // ... and, from another GPU, fetched
         PipeDev &w = p->devs[(size_t)src_dev];
-        if (src_slot >= 0) TRYS(hipStreamWaitEvent(v.st_comp, p->slots[(size_t)src_slot].ev[EV_PREP], 0));
-        TRYS(hipMemcpyPeerAsync(v.sh.carry[bno % p->ncarry], c->device, w.sh.carry[bno % p->ncarry], w.c->device, sizeof(CarryState), v.st_comp));
+        TRYS(hipMemcpyPeerAsync(v.sh.carry[bno % p->ncarry], c->device, w.sh.carry[bno % p->ncarry], w.c->device, sizeof(CarryState), s.comp));
     }
     if (mode != MODE_PREPARED) {
-        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, v.sh, bno, nbytes, format, first_index, pair_split ? 0xFFFFFFFFu : p->read_end, readset, mr, pair_split, pair_split ? n / 2 : 0, v.st_comp));
-        else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, v.st_comp));
-        TRYR(prep_enqueue_filter(c, p->k, d, v.sh, bno, mr, true, 0, v.st_comp));
-        if (p->o.flags & BASAL_PIPE_PAIRS) TRYR(prep_enqueue_pair_fix(c, d, n / 2, v.st_comp));
+        if (mode == MODE_TEXT) TRYR(prep_enqueue_index_text(c, d, v.sh, bno, nbytes, format, first_index, pair_split ? 0xFFFFFFFFu : p->read_end, readset, mr, pair_split, pair_split ? n / 2 : 0, s.comp));
+        else TRYS(hipMemcpyAsync(&d.cnt->n_reads, &s.n_host, sizeof(uint32_t), hipMemcpyHostToDevice, s.comp));
+        TRYR(prep_enqueue_filter(c, p->k, d, v.sh, bno, mr, true, 0, s.comp));
+        if (p->o.flags & BASAL_PIPE_PAIRS) TRYR(prep_enqueue_pair_fix(c, d, n / 2, s.comp));
     }
-    TRYS(hipEventRecord(s.ev[EV_PREP], v.st_comp));
+    TRYS(hipEventRecord(s.ev[EV_PREP], s.comp));
     TRYR(queue_align(p, s));
-    TRYS(hipEventRecord(s.ev[EV_ALIGN], v.st_comp));
+    TRYS(hipEventRecord(s.ev[EV_ALIGN], s.comp));
     if (mode != MODE_PREPARED) TRYR(queue_format(p, s));
-    TRYS(hipEventRecord(s.ev[EV_FORMAT], v.st_comp));
+    TRYS(hipEventRecord(s.ev[EV_FORMAT], s.comp));
     // copies out: the counters (and the guard ledger) always; the output itself once its size is known
     TRYS(hipStreamWaitEvent(v.st_cnt, s.ev[EV_FORMAT], 0));
     TRYS(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, v.st_cnt));
@@ -517,6 +527,7 @@ extern "C" int basal_pipe_rewind(basal_pipe_t *p) {
         HIP_TRYQ(hipSetDevice(v.c->device));
         HIP_TRYQ(hipStreamSynchronize(v.st_in));
         HIP_TRYQ(hipStreamSynchronize(v.st_comp));
+        HIP_TRYQ(hipStreamSynchronize(v.st_comp2));
         HIP_TRYQ(hipStreamSynchronize(v.st_out));
         HIP_TRYQ(hipStreamSynchronize(v.st_cnt));
     }
@@ -589,7 +600,7 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             const bool stream_small = d.stream && cn.stream_used > d.stream_cap, out_small = cn.out_bytes > d.out_cap;
             const bool recs_small = d.pe_recs && cn.pe_recs_used > d.pe_recs_cap;
             if (!stream_small && !out_small && !recs_small && !(cn.irregular & 2u)) break;
-            HIP_TRYQ(hipStreamSynchronize(v.st_comp));
+            HIP_TRYQ(hipStreamSynchronize(s.comp));
             HIP_TRYQ(hipStreamSynchronize(v.st_cnt));
             if (stream_small || (cn.irregular & 2u)) {
                 hipFree(d.stream);
@@ -619,14 +630,14 @@ extern "C" int basal_pipe_collect(basal_pipe_t *p, const void **out, uint64_t *n
             BatchCounters z = cn;
             z.n_aligned = z.n_unique = z.n_multiple = 0; z.out_bytes = 0; z.irregular &= ~2u;
             if (stream_small || (cn.irregular & 2u)) z.stream_used = 0;
-            HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, v.st_comp));
-            HIP_TRYQ(hipStreamSynchronize(v.st_comp));
+            HIP_TRYQ(hipMemcpyAsync(d.cnt, &z, sizeof z, hipMemcpyHostToDevice, s.comp));
+            HIP_TRYQ(hipStreamSynchronize(s.comp));
             if (stream_small || (cn.irregular & 2u)) { int rc = queue_align(p, s); if (rc) return rc; }
             { int rc = queue_format(p, s); if (rc) return rc; }
-            HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, v.st_comp));
-            HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, v.st_comp));
-            HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), v.st_comp));
-            HIP_TRYQ(hipStreamSynchronize(v.st_comp));
+            HIP_TRYQ(hipMemcpyAsync(s.h_cnt, d.cnt, sizeof(BatchCounters), hipMemcpyDeviceToHost, s.comp));
+            HIP_TRYQ(hipMemcpyAsync(s.h_guard, d.counter + 1, 24 * sizeof(unsigned int), hipMemcpyDeviceToHost, s.comp));
+            HIP_TRYQ(hipMemsetAsync(d.counter + 1, 0, 24 * sizeof(unsigned int), s.comp));
+            HIP_TRYQ(hipStreamSynchronize(s.comp));
             if ((ret = basal_report_guard(s.h_guard))) break;
         }
     }

@@ -91,6 +91,25 @@ def test_cli_two_ranks_one_pipeline_matches_golden(name, gpus, pipe_bytes, tmp_p
     assert got == H.golden_sam(name)
 
 
+@pytest.mark.parametrize("name", ["varlen_trim", "varlen_s16", "tdel_pipeline", "rep_r2_w10"])
+@pytest.mark.parametrize("one_stream", ["0", "1"])
+def test_cli_two_kernel_streams_match_golden(name, one_stream, tmp_path):
+    """Round 4: consecutive batches' kernels alternate between two kernel streams of the GPU (the end of one align launch overlaps the next batch's
+    kernels); what orders them is the carry state's event, as between GPUs.  Small batches of the fixtures whose reads inherit state across batches,
+    with both streams (default) and with one (BASAL_PIPE_ONE_STREAM=1): the golden SAMs either way."""
+    import gzip
+    fa, fq, _, _ = H.fixture_paths(name)
+    plain = tmp_path / os.path.basename(fq)[:-3]
+    plain.write_bytes(gzip.open(fq, "rb").read())
+    out = tmp_path / "o.sam"
+    env = dict(os.environ, BASAL_PIPE_BYTES="6000")
+    if one_stream == "1":
+        env["BASAL_PIPE_ONE_STREAM"] = "1"
+    r = subprocess.run([BASAL_BIN, "-a", str(plain), "-d", fa] + H.MANIFEST[name]["flags"] + ["-p", "4", "-o", str(out)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "".join(l for l in open(out) if not l.startswith("@PG")) == H.golden_sam(name)
+
+
 @pytest.mark.parametrize("name", [n for n in H.MANIFEST if H.MANIFEST[n]["pe"]])
 def test_cli_two_ranks_paired_end_matches_golden(name, tmp_path):
     """`basal -b ... -G 0,0`: the paired-end pipeline over two cores, 32 pairs per batch (the carry state of both mates' slots crosses from rank

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--runs", type=int, default=2)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--realistic", action="store_true", help="the hg38-like repeat landscape (bench.py's default genome) instead of the uniform stand-in")
     ap.add_argument("--pairs", type=int, default=0, help="paired-end: this many read pairs (two FASTQ files, basal -a/-b) instead of --reads single reads")
     a = ap.parse_args()
     import numpy as np
@@ -43,7 +44,7 @@ def main():
     dev = torch.device("cuda", 0)
     p = B.Params(a.rule, ["-M", a.rule])
     t0 = time.time()
-    G = synth_gpu.make_genome(p, dev, scale=a.scale, seed=1)
+    G = synth_gpu.make_genome(p, dev, scale=a.scale, seed=1, repeat_copies=40000, realistic=a.realistic)
     synth_files.write_fasta(fa, G)
     frm = "ACGT".index(a.rule[0])
     tos = [t for t in a.rule[2:] if t in "ACGT"]
