@@ -607,6 +607,10 @@ def main():
         torch.cuda.synchronize()
         hb = d_bases[: args.batch * read_len].cpu().numpy()
         hd = descs[: args.batch].copy()
+        # (one kernel stream here: the pipe would alternate consecutive batches' kernels between two streams so that one launch's tail overlaps the next
+        # launch -- DESIGN 4.3 -- and overlapping launches would make this process's per-launch durations, which the roofline is priced with and
+        # rocprofv3 --kernel-trace averages, something other than the time one launch takes)
+        os.environ["BASAL_PIPE_ONE_STREAM"] = "1"
         pipe = B.Pipe(core, depth=3, max_reads=args.batch, max_bytes=args.batch * read_len + 4096, output=B.PIPE_OUT_RESULTS)
         for _ in range(3):  # fill the three slots' page-locked buffers once (the caller's reads; this also faults their pages in), untimed
             bl, rw = pipe.acquire()
