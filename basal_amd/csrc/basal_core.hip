@@ -3247,10 +3247,9 @@ extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *base
     if (n == 0) return BASAL_OK;
     HIP_TRY(hipSetDevice(c->device));
     uint32_t max_len = 0;
-    if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_pairs_batch", &max_len)) return vrc;
+    if (nbases > 0xFFFFFFFFull) { g_err = "align_pairs_batch: more than 4 GiB of bases in one batch (basal_read.seq_off is 32-bit); split the batch"; return BASAL_EINVAL; }
     LaneHold hold(c, true);  // (the pairing buffers are the core's: one paired-end call at a time)
     if (!hold.L) return BASAL_EDEVICE;
-    if (max_len == 0) max_len = 1;
     int rc;
     if ((rc = grow(c->lane0.d_bases, c->lane0.cap_bases, nbases + 64))) return rc;
     if (n > c->lane0.cap_reads) { hipFree(c->lane0.d_results); c->lane0.d_results = nullptr; }
@@ -3264,6 +3263,10 @@ extern "C" int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *base
     HIP_TRY(hipMemcpyAsync(c->lane0.d_bases, bases, nbases, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->lane0.d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
     if (nstale) HIP_TRY(hipMemcpyAsync(c->lane0.d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
+    // the descriptors are checked while the copies run (page-locked caller buffers: 2 M descriptors take the host as long as their bases take the link);
+    // nothing is launched on a batch that fails the check
+    if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_pairs_batch", &max_len)) { hipStreamSynchronize(s); return vrc; }
+    if (max_len == 0) max_len = 1;
     static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
     // the hit streams stay on the device: a first guess of their size, doubled until every mate's log fits
     uint64_t stream_cap = c->lane0.cap_stream > (uint64_t)n * 8 + 4096 ? c->lane0.cap_stream : (uint64_t)n * 8 + 4096;

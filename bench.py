@@ -153,20 +153,26 @@ def bench_pairs(args):
     batches = []
     for k in range(min(args.steps + args.warmup, 3)):
         b1, b2 = synth_gpu.make_pairs(G, npairs, dev, read_len=rl, seed=40 + k)
-        hb = torch.stack([b1.view(npairs, rl), b2.view(npairs, rl)], dim=1).reshape(-1).cpu().numpy()  # a0 b0 a1 b1 ...
-        d = np.zeros(2 * npairs, bc.READ_DTYPE)
+        # (page-locked host buffers, as a host feeding a GPU keeps them: the copies then run at the link's rate)
+        hb_t = torch.empty(2 * npairs * rl, dtype=torch.uint8, pin_memory=True)
+        hb_t.copy_(torch.stack([b1.view(npairs, rl), b2.view(npairs, rl)], dim=1).reshape(-1))  # a0 b0 a1 b1 ...
+        hb = hb_t.numpy()
+        d_t = torch.zeros(2 * npairs * bc.READ_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True)
+        d = d_t.numpy().view(bc.READ_DTYPE)
         d["seq_off"] = np.arange(2 * npairs, dtype=np.uint64) * rl
         d["index"] = np.repeat(np.arange(npairs, dtype=np.uint32) + k * npairs, 2)
         d["len"], d["max_snp"], d["stale_idx"] = rl, ms.value, B.STALE_NONE
         d["readset"] = np.tile(np.array([1 | B.READ_ALLMODES, 2 | B.READ_ALLMODES], np.uint8), npairs)
-        batches.append((hb, d))
-    pairs = np.zeros(npairs, PE_PAIR)
-    recs = np.zeros(2 * npairs + 4096, PE_REC)
+        batches.append((hb, d, hb_t, d_t))
+    pairs_t = torch.zeros(npairs * PE_PAIR.itemsize, dtype=torch.uint8, pin_memory=True)
+    recs_t = torch.zeros((2 * npairs + 4096) * PE_REC.itemsize, dtype=torch.uint8, pin_memory=True)
+    pairs = pairs_t.numpy().view(PE_PAIR)
+    recs = recs_t.numpy().view(PE_REC)
     core.set_timing(True)
     st = (C.c_uint32 * 9)()
 
     def step(i):
-        hb, d = batches[i % len(batches)]
+        hb, d = batches[i % len(batches)][:2]
         used = C.c_uint64()
         cy = np.zeros((2, 2), np.uint8)
         bc._check(L.basal_core_align_pairs_batch(core.h, hb.ctypes.data, len(hb), d.ctypes.data, npairs, None, 0, pairs.ctypes.data, recs.ctypes.data, len(recs),
