@@ -3169,7 +3169,7 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     if (stream_used) *stream_used = 0;
     if (n == 0) return BASAL_OK;
     uint32_t max_len = 0;
-    if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_batch", &max_len)) return vrc;
+    if (nbases > 0xFFFFFFFFull) { g_err = "align_batch: more than 4 GiB of bases in one batch (basal_read.seq_off is 32-bit); split the batch"; return BASAL_EINVAL; }
     LaneHold hold(c);  // a free lane (this call may run beside others on the same core); given back when the call returns
     if (!hold.L) return BASAL_EDEVICE;
     CoreLane &L = *hold.L;
@@ -3195,6 +3195,8 @@ extern "C" int basal_core_align_batch(basal_core_t *c, const uint8_t *bases, uin
     HIP_TRY(hipMemcpyAsync(L.d_reads, reads, (size_t)n * sizeof(basal_read), hipMemcpyHostToDevice, s));
     if (nstale) HIP_TRY(hipMemcpyAsync(L.d_stales, stales, (size_t)nstale * sizeof(basal_stale), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(L.d_used, 0, sizeof(unsigned long long), s));
+    // (the descriptors are checked while the copies run; nothing is launched on a batch that fails the check)
+    if (int vrc = basal_validate_batch(c->p, reads, n, nbases, stales, nstale, "align_batch", &max_len)) { hipStreamSynchronize(s); return vrc; }
     static const uint8_t zero_carry[2][2] = {{0, 0}, {0, 0}};
     rc = launch_align(c, L.d_bases, nbases, L.d_reads, n, nstale ? L.d_stales : nullptr, nstale, max_len, stream_mode, L.d_results, L.d_stream, stream_cap, L.d_used,
                       carry ? (const uint8_t(*)[2])carry : zero_carry, s, ex);
