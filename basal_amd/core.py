@@ -109,6 +109,7 @@ SYMBOLS = [
     ("basal_core_align_batch", _i, [_vp, _vp, _u64, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _P(_u64), _vp]),
     ("basal_core_align_batch_device", _i, [_vp, _vp, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
     ("basal_core_sync_check", _i, [_vp]),
+    ("basal_core_occupancy_report", _i, [C.c_char_p, C.c_size_t]),
     ("basal_core_set_timing", _i, [_vp, _i]),
     ("basal_core_last_kernel_ms", C.c_float, [_vp]),
     ("basal_core_last_pair_ms", C.c_float, [_vp]),

@@ -199,6 +199,17 @@ __device__ __forceinline__ uint32_t bsel(uint32_t s, uint32_t a, uint32_t b) { r
 // mismatch bitmap of a window: per base the mask of the reference letter (2 * hi + lo) that is there
 __device__ __forceinline__ uint64_t plane_mismatch(uint64_t hi, uint64_t lo, const uint64_t m[4]) { return bsel(lo, bsel(hi, m[3], m[1]), bsel(hi, m[2], m[0])); }
 __device__ __forceinline__ uint32_t plane_mismatch(uint32_t hi, uint32_t lo, const uint32_t m[4]) { return bsel(lo, bsel(hi, m[3], m[1]), bsel(hi, m[2], m[0])); }
+// The same for a SHIFTED window whose vacated bits are masked off afterwards: written as (s & a) | (~s & b) the compiler folds that mask into the
+// outer select and spends four instructions per word on it (and, xor, and, or); the instruction itself keeps it at one.
+__device__ __forceinline__ uint32_t bfi_hw(uint32_t s, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(s), "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint64_t plane_mismatch_sh(uint64_t hi, uint64_t lo, const uint64_t m[4]) {
+    const uint64_t x = bsel(hi, m[3], m[1]), y = bsel(hi, m[2], m[0]);
+    return ((uint64_t)bfi_hw((uint32_t)(lo >> 32), (uint32_t)(x >> 32), (uint32_t)(y >> 32)) << 32) | bfi_hw((uint32_t)lo, (uint32_t)x, (uint32_t)y);
+}
 
 // bits [start, start + 64) of an NW-word bit string (LSB first) kept as pl[1..NW] between two zero words; zero outside it
 template <int NW>
@@ -273,11 +284,20 @@ struct HeavyLds<true, NWT> {
 
 // PE (the paired-end instantiations of the standard kernels): a mate runs every mode, so several modes' seeds (BASAL_PE_ENT entries: four modes at
 // -I 4) are set up and streamed as ONE group, and the log remembers where its records were found (HitState::g)
+// (its own base, PE only: eight bytes more per wave took the standard GAP kernels from 25 to 26 LDS allocation units of 1 280 B per block -- and from five
+// blocks per CU to four, 101 -> 114 ms per 10 M reads of config 4)
+template <bool PE>
+struct StageLds {};
+template <>
+struct StageLds<true> {
+    uint32_t stg_n, stg_mask;  // hit-stream records staged for the reads of this chunk (stream_flush), and which of the chunk's reads they belong to
+};
 template <int NWT, bool GAP, bool HEAVY = false, bool PE = false>
-struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, EndLds<GAP && HEAVY> {
+struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, EndLds<GAP && HEAVY>, StageLds<PE> {
     static constexpr int NW = NWT;
     static constexpr bool PEK = PE;
-    static constexpr int MAXPOS = NWT * 32;
+    // (seed positions of a read: fewer than BASAL_MAXREADLEN; 496 instead of 512 keeps the 16-word HEAVY kernels' block at 42 LDS allocation units, three blocks per CU)
+    static constexpr int MAXPOS = NWT * 32 > BASAL_MAXREADLEN + 16 ? BASAL_MAXREADLEN + 16 : NWT * 32;
     uint64_t q[2][3][NWT + 1];  // [chain][bases, valid, convert-to][word]; last word always 0
     uint32_t seed[2][MAXPOS];   // XT hash; bit 31: seed window contains a non-ACGT base
     uint32_t cnt[2][MAXPOS];    // index2[seed].n[0]
@@ -292,7 +312,6 @@ struct WaveLds : GapLds<NWT, GAP>, HeavyLds<HEAVY, NWT>, SurvLds<GAP || HEAVY>, 
     uint32_t nhit[2][16];  // x_cur_n_hit[chain][level]
     uint8_t start_arr[2][16];
     uint8_t order[2][16];
-    uint32_t stg_n, stg_mask;  // hit-stream records staged for the reads of this chunk (stream_flush), and which of the chunk's reads they belong to
 };
 
 // LDS written by one lane and read by the others of the SAME wave: LDS ops of a wave execute in
@@ -2143,12 +2162,12 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
                             for (uint32_t tg = 1; tg <= BASAL_MAXGAPS; tg++) {  // tt = 2 tg - 1 (shift -tg), then tt = 2 tg (shift +tg); wave-uniform conditions
                                 if (tg <= cx.gap && st.thr >= 1 + tg) {
                                     // shift -t: read base i against window base i - t
-                                    const uint64_t Dm = plane_mismatch(Lhi << tg, Llo << tg, P.ml) & (~0ULL << tg);
+                                    const uint64_t Dm = plane_mismatch_sh(Lhi << tg, Llo << tg, P.ml) & (~0ULL << tg);
                                     const uint32_t dm = plane_mismatch(Shi << tg, Slo << tg, P.ms) & (~0u << tg);
                                     if constexpr (HEAVY) gk |= popc64((Dm & (D0l | El)) | F0l) + (uint32_t)__popc((dm & (D0s | Es)) | F0s) <= st.thr - 1;
                                     else gk |= popc64(D0l & Dm) + (uint32_t)__popc(D0s & dm) <= st.thr - 1;
                                     // shift +t
-                                    const uint64_t Dp = plane_mismatch(Lhi >> tg, Llo >> tg, P.ml) & (~0ULL >> tg);
+                                    const uint64_t Dp = plane_mismatch_sh(Lhi >> tg, Llo >> tg, P.ml) & (~0ULL >> tg);
                                     const uint32_t dp = plane_mismatch(Shi >> tg, Slo >> tg, P.ms) & (~0u >> tg);
                                     if constexpr (HEAVY) gk |= popc64((Dp & (D0l | El)) | F0l) + (uint32_t)__popc((dp & (D0s | Es)) | F0s) <= st.thr - 1 - tg;
                                     else gk |= popc64(D0l & Dp) + (uint32_t)__popc(D0s & dp) <= st.thr - 1 - tg;
@@ -2555,7 +2574,7 @@ __global__ __launch_bounds__(256, waves_per_simd(NWT, GAP, HEAVY, PE)) void alig
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     WaveLds<NWT, GAP, HEAVY, PE> &L = s_w[wv];
-    if (lane0(lane)) L.stg_n = L.stg_mask = 0;
+    if constexpr (PE) if (lane0(lane)) L.stg_n = L.stg_mask = 0;
     if (lane <= NWT) {  // zero the pad words once
         for (int c = 0; c < 2; c++)
             for (int p = 0; p < 3; p++) L.q[c][p][lane] = 0;
@@ -2690,6 +2709,46 @@ kernel_fn pick_kernel(bool newrule, bool gap, bool heavy = false, bool pe = fals
 
 extern "C" const char *basal_last_error(void) { return g_err.c_str(); }
 namespace basal { void set_error(const std::string &s) { g_err = s; } }
+
+// Instrumentation: for every align_kernel instantiation one text line "nwt newrule gap heavy pe assumed fit slack": the blocks per CU its launch bounds
+// ask for (waves_per_simd: 256-thread blocks, one wave per SIMD each), the blocks that fit (registers by the runtime's occupancy answer, LDS by the
+// chip's allocation unit), and how many more bytes of LDS a block could take before it loses one. Returns the number of kernels, or a
+// negative error. (tests/test_gpu_parity.py pins the `fit` column: a kernel that silently loses a block per CU loses its share of the waves.)
+namespace {
+// LDS is handed out in units of 1 280 B on this chip (128 units per CU; tools/microbench_lds_alloc.hip: a block of 32 000 B is resident five times per
+// CU, one of 32 001 B four times) -- which the occupancy API does not know (it answers 5 up to 32 768 B).
+constexpr size_t LDS_UNIT = 1280, LDS_UNITS_PER_CU = 128;
+int blocks_that_fit(kernel_fn k, size_t dyn_lds) {
+    int fit = 0;
+    hipFuncAttributes a;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, k, 256, dyn_lds) != hipSuccess || hipFuncGetAttributes(&a, (const void *)k) != hipSuccess) return -1;
+    const size_t units = (a.sharedSizeBytes + dyn_lds + LDS_UNIT - 1) / LDS_UNIT;
+    if (units && (int)(LDS_UNITS_PER_CU / units) < fit) fit = (int)(LDS_UNITS_PER_CU / units);
+    return fit;
+}
+}  // namespace
+extern "C" int basal_core_occupancy_report(char *text, size_t cap) {
+    std::string out;
+    int n = 0;
+    for (int nwt : {4, 8, 16})
+        for (int v = 0; v < 10; v++) {
+            const bool nr = v & 1, gp = (v >> 1) == 1 || (v >> 1) == 3, hv = (v >> 1) >= 2 && (v >> 1) <= 3, pe = (v >> 1) == 4;
+            kernel_fn k = nwt == 4 ? pick_kernel<4>(nr, gp, hv, pe) : nwt == 8 ? pick_kernel<8>(nr, gp, hv, pe) : pick_kernel<16>(nr, gp, hv, pe);
+            const int fit = blocks_that_fit(k, 0);
+            if (fit < 0) { g_err = "hipOccupancyMaxActiveBlocksPerMultiprocessor failed"; return BASAL_EDEVICE; }
+            size_t lo = 0, hi = 65536;  // the largest dynamic LDS size that keeps `fit` blocks
+            while (lo < hi) {
+                const size_t mid = (lo + hi + 1) / 2;
+                if (blocks_that_fit(k, mid) >= fit) lo = mid; else hi = mid - 1;
+            }
+            char line[96];
+            snprintf(line, sizeof line, "%d %d %d %d %d %d %d %zu\n", nwt, (int)nr, (int)gp, (int)hv, (int)pe, waves_per_simd(nwt, gp, hv, pe), fit, lo);
+            out += line;
+            n++;
+        }
+    if (text && cap) snprintf(text, cap, "%s", out.c_str());
+    return n;
+}
 
 static uint32_t pow3(uint32_t k) {
     uint32_t t = 1;
@@ -2974,6 +3033,13 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
     cx.total_kmers = c->total_kmers; cx.nlocs = (uint32_t)c->nlocs; cx.nwords = c->nwords + 64; cx.nbases = nbases_dev;
     const char *env = getenv("BASAL_BLOCKS_PER_CU");
     uint32_t per_cu = env ? (uint32_t)atoi(env) : (uint32_t)waves_per_simd(nwt, gp, hv, pe);
+    if (!env) {  // (no more blocks than are resident at once: the kernels whose registers or LDS fit fewer than their launch bounds ask for)
+        static std::atomic<int> fit_of[3][2][2][2][2];  // 0 = not asked yet (every GPU of a node answers the same)
+        std::atomic<int> &slot = fit_of[nwt == 4 ? 0 : nwt == 8 ? 1 : 2][nr][gp][hv][pe];
+        int fit = slot.load(std::memory_order_relaxed);
+        if (!fit) { fit = blocks_that_fit(k, 0); slot.store(fit, std::memory_order_relaxed); }
+        if (fit > 0 && (uint32_t)fit < per_cu) per_cu = (uint32_t)fit;
+    }
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     uint32_t grid = (uint32_t)c->prop.multiProcessorCount * per_cu;

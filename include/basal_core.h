@@ -304,6 +304,11 @@ int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *bases, uint64_t
                                  uint32_t nstale, basal_pe_pair *pairs_out, basal_pe_rec *recs_out, uint64_t recs_cap, uint64_t *recs_used, uint32_t stats[9],
                                  uint8_t carry[2][2]);
 
+/* Instrumentation (no reference counterpart): one line per align-kernel instantiation in text[cap], "nwt newrule gap heavy pe assumed fit slack" --
+ * the blocks per CU its launch bounds ask for, the blocks the runtime says fit on this GPU, the LDS bytes a block could still grow by. Returns the
+ * number of lines. */
+int basal_core_occupancy_report(char *text, size_t cap);
+
 /* ---- several GPUs of one node: reads sharded by read number, hit records gathered with RCCL ----
  * The reference fans batches out to host threads (main.cpp:60-92); this fans the reads of a batch out to GPUs. Every GPU holds the whole
  * reference + index, aligns a contiguous range of the batch's reads, and ONE ncclGather per batch moves the 32-byte records to GPU 0. */

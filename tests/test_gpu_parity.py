@@ -42,6 +42,24 @@ def run_product(name, stream_mode, extra_flags=(), batch=None):
     return p, ref, core, recs, results, stream
 
 
+def test_kernels_keep_their_blocks_per_cu():
+    """The persistent grids are sized by the blocks per CU that fit; a kernel that loses one (LDS, registers) loses its share of the waves without
+    any error (round 4: eight bytes of LDS per wave cost the standard GAP kernels a block per CU and 12 %). The runtime's answer is pinned here."""
+    buf = C.create_string_buffer(8192)
+    n = B.core.lib().basal_core_occupancy_report(buf, len(buf))
+    assert n == 30, B.core.lib().basal_last_error()
+    rows = [tuple(int(x) for x in l.split()) for l in buf.value.decode().splitlines()]
+    print(buf.value.decode())
+    expect = {  # (nwt, gap, heavy, pe) -> blocks per CU
+        (4, 0, 0, 0): 8, (4, 1, 0, 0): 5, (4, 0, 1, 0): 5, (4, 1, 1, 0): 4, (4, 0, 0, 1): 8,
+        (8, 0, 0, 0): 5, (8, 1, 0, 0): 2, (8, 0, 1, 0): 4, (8, 1, 1, 0): 3, (8, 0, 0, 1): 5,
+        (16, 0, 0, 0): 3, (16, 1, 0, 0): 2, (16, 0, 1, 0): 3, (16, 1, 1, 0): 2, (16, 0, 0, 1): 3,
+    }
+    bad = ["nwt %d newrule %d gap %d heavy %d pe %d: %d blocks per CU fit, %d expected (launch bounds ask for %d, LDS slack %d B)" % (r[0], r[1], r[2], r[3], r[4], r[6], expect[(r[0], r[2], r[3], r[4])], r[5], r[7])
+           for r in rows if r[6] < expect[(r[0], r[2], r[3], r[4])]]
+    assert not bad, "\n".join(bad)
+
+
 @pytest.mark.parametrize("name", H.SE)
 def test_hit_logs_match_oracle(name):
     """Every stored hit of every read, in insertion order, with level/chain/mode: the whole AddHit history."""

@@ -38,6 +38,7 @@ def main():
                 bad += 1
                 break
     name = None
+    usage = {}
     for l in r.stderr.split("\n"):
         m = re.search(r"Function Name: (\S+)", l)
         if m:
@@ -45,6 +46,23 @@ def main():
         m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\d+)", l)
         if m and name:
             print("%-60s %-28s %s" % (name[-60:], m.group(1), m.group(2)))
+            usage.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    # LDS is handed out in units of 1 280 B on gfx950 (160 KB = 128 units per CU): a block of four waves one unit over costs a whole block per CU.
+    # (Measured, round 4: 8 bytes more per wave took align_kernel<4,*,GAP> from 25 to 26 units, from five blocks per CU to four, 101 -> 114 ms.)
+    # The compiler's occupancy figure (registers) is what the launch code counts on: blocks per CU = waves per SIMD for 256-thread blocks.
+    for name, u in usage.items():
+        if "align_kernel" not in name or "LDS Size [bytes/block]" not in u or "Occupancy [waves/SIMD]" not in u:
+            continue
+        units = -(-u["LDS Size [bytes/block]"] // 1280)
+        m = re.search(r"align_kernelILi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+        want = u["Occupancy [waves/SIMD]"]
+        if m:  # the HEAVY GAP kernels and the 8-/16-word GAP kernels are launched with fewer waves than their registers allow (waves_per_simd)
+            nwt, gap, heavy = int(m.group(1)), m.group(3) == "1", m.group(4) == "1"
+            if gap and heavy:
+                want = min(want, {4: 4, 8: 3, 16: 2}[nwt])
+        if units * want > 128:
+            print("LDS: %s takes %d units of 1280 B per block, %d blocks per CU need %d > 128" % (name[-60:], units, want, units * want))
+            bad += 1
     # a device function that was NOT inlined into its kernel (it then takes LDS and global pointers as generic ones: flat loads, a stack of
     # several hundred bytes per lane) -- every function of this file is meant to end up inside an align_kernel instantiation or a small kernel
     for l in lines:
