@@ -2750,6 +2750,37 @@ extern "C" int basal_core_occupancy_report(char *text, size_t cap) {
     return n;
 }
 
+// Experiment hook (tools/probe_placement.py; not in the header): move one class of the core's long-lived buffers to freshly allocated memory -- new
+// allocation, device copy, the old one freed -- so that its physical placement changes and nothing else. which: 0 locs, 1 flank words, 2 seed words,
+// 3 the two k-mer tables, 4 the reference strands, 5 the per-wave hit logs.
+extern "C" int basal_core_debug_replace(basal_core_t *c, int which) {
+    auto move = [&](void **pp) -> int {
+        if (!*pp) return BASAL_OK;
+        size_t n = 0;
+        HIP_TRY(hipMemPtrGetInfo(*pp, &n));
+        void *q = nullptr;
+        HIP_TRY(hipMalloc(&q, n));
+        HIP_TRY(hipMemcpy(q, *pp, n, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(*pp));
+        *pp = q;
+        return BASAL_OK;
+    };
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = BASAL_OK;
+    switch (which) {
+    case 0: rc = move((void **)&c->d_locs); break;
+    case 1: rc = move((void **)&c->d_flank_a); c->d_flank_b = c->d_flank_a ? c->d_flank_a + c->nlocs + 64 : nullptr; break;
+    case 2: rc = move((void **)&c->d_seedw); break;
+    case 3: rc = move((void **)&c->d_koff); if (!rc) rc = move((void **)&c->d_knfwd); break;
+    case 4: rc = move((void **)&c->d_xref[0]); if (!rc) rc = move((void **)&c->d_xref[1]); break;
+    case 5: rc = move((void **)&c->d_scratch); break;
+    default: g_err = "basal_core_debug_replace: which = 0..5"; return BASAL_EINVAL;
+    }
+    return rc;
+}
+
 static uint32_t pow3(uint32_t k) {
     uint32_t t = 1;
     for (uint32_t i = 0; i < k; i++) t *= 3;
@@ -3052,6 +3083,9 @@ static int launch_align(basal_core *c, const void *d_bases, uint64_t nbases_dev,
         HIP_TRY(hipStreamSynchronize(s));
         fprintf(stderr, "[basal debug] launching align kernel NWT=%d newrule=%d gap=%d heavy=%d grid=%u n=%u nstale=%u max_kmer_num=%u nlocs=%llu\n", nwt, (int)nr,
                 (int)gp, (int)hv, grid, n, cx.nstale, cx.max_kmer_num, (unsigned long long)c->nlocs);
+        fprintf(stderr, "[basal debug] buffers: xref %p %p koff %p knfwd %p locs %p flank_a %p flank_b %p seedw %p scratch %p counter %p results %p bases %p\n", (void *)c->d_xref[0],
+                (void *)c->d_xref[1], (void *)c->d_koff, (void *)c->d_knfwd, (void *)c->d_locs, (void *)c->d_flank_a, (void *)c->d_flank_b, (void *)c->d_seedw, (void *)cx.scratch,
+                (void *)counter, d_results, d_bases);
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, cx);
     HIP_TRY(hipGetLastError());
