@@ -1,6 +1,6 @@
 // Does plain random streaming depend on where hipMalloc put a buffer? N buffers of S GB, all resident; for each, every wave of a full grid reads random 1 KB chunks
 // (64 lanes x 16 B, non-temporal -- the shape of the long-list stream of align_kernel<.., HEAVY>) and the GB/s are printed, twice, so that a buffer's figure can be
-// told from run-to-run noise.   hipcc --offload-arch=gfx950 -O2 tools/microbench_placement.hip -o /tmp/mbp && /tmp/mbp [S_GB] [N]
+// told from run-to-run noise.   hipcc --offload-arch=gfx950 -O2 tools/microbench_placement.hip -o /tmp/mbp && /tmp/mbp [S_GB] [N] [contiguous 0/1]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -25,13 +25,21 @@ __global__ __launch_bounds__(256) void gather(const v4u *buf, unsigned long long
 int main(int argc, char **argv) {
     const double gb = argc > 1 ? atof(argv[1]) : 12.0;
     const int n = argc > 2 ? atoi(argv[2]) : 8;
+    const bool contig = argc > 3 && atoi(argv[3]) != 0;
     const size_t bytes = (size_t)(gb * 1e9) / 1024 * 1024;
     const unsigned long long nchunks = bytes / 1024;
     std::vector<v4u *> bufs(n);
     unsigned *sink;
     CHECK(hipMalloc(&sink, 4));
     for (int b = 0; b < n; b++) {
-        CHECK(hipMalloc(&bufs[b], bytes));
+        if (contig) {  // physically contiguous (best effort); falls back to the ordinary allocation
+            if (hipExtMallocWithFlags((void **)&bufs[b], bytes, hipDeviceMallocContiguous) != hipSuccess) {
+                (void)hipGetLastError();
+                printf("buffer %d: no contiguous block, ordinary allocation\n", b);
+                CHECK(hipMalloc(&bufs[b], bytes));
+            }
+        } else
+            CHECK(hipMalloc(&bufs[b], bytes));
         CHECK(hipMemset(bufs[b], b + 1, bytes));
     }
     CHECK(hipDeviceSynchronize());
