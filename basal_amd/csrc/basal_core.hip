@@ -2523,7 +2523,7 @@ __device__ __forceinline__ void process_read(const DevCtx &cx, WaveLds<NWT, GAP,
 #define BASAL_W8NG 5
 #endif
 #ifndef BASAL_W8G
-#define BASAL_W8G 4
+#define BASAL_W8G 3  // (asked for four, the compiler kept 189 registers and the kernels ran two waves; three = 168 registers, one spill: 150-base -g 2 reads 50 -> 62.5 Mreads/s)
 #endif
 #ifndef BASAL_W16NG
 #define BASAL_W16NG 4
