@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--hold", type=float, default=0.0, help="GB kept allocated from one round to the next (shifts the placement)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--which", default="", help="comma list of buffer classes to move one at a time (basal_core_debug_replace: 0 locs, 1 flank words, 2 seed words, 3 k-mer tables, 4 reference, 5 hit logs)")
+    ap.add_argument("--pre", type=float, default=0.0, help="GiB allocated (and kept) before the first core is created")
     ap.add_argument("--pair", action="store_true", help="two cores resident at once, launches alternating")
     a = ap.parse_args()
     import torch
@@ -63,6 +64,9 @@ def main():
     d_used = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     held = []
+    if a.pre > 0:  # a blocker allocated before the first core: shifts where the core's buffers land in HBM
+        held.append(torch.empty(int(a.pre * 2 ** 30), dtype=torch.uint8, device=dev))
+        print("blocker of %.0f GiB at %#x" % (a.pre, held[-1].data_ptr()), flush=True)
 
     def make_core():
         core = B.Core(params, 0)
