@@ -110,6 +110,10 @@ SYMBOLS = [
     ("basal_core_align_batch_device", _i, [_vp, _vp, _vp, _u32, _vp, _u32, _i, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
     ("basal_core_sync_check", _i, [_vp]),
     ("basal_core_occupancy_report", _i, [C.c_char_p, C.c_size_t]),
+    ("basal_core_placement_fork", _i, [_vp]),
+    ("basal_core_placement_swap", _i, [_vp]),
+    ("basal_core_placement_commit", _i, [_vp]),
+    ("basal_core_move_buffers", _i, [_vp, _i]),
     ("basal_core_set_timing", _i, [_vp, _i]),
     ("basal_core_last_kernel_ms", C.c_float, [_vp]),
     ("basal_core_last_pair_ms", C.c_float, [_vp]),
@@ -186,7 +190,7 @@ def lib():
                              "(there is no fallback implementation)" % path)
         _lib = C.CDLL(path)
         for name, res, args in SYMBOLS:
-            if os.environ.get("BASAL_LIB") and not hasattr(_lib, name) and name in ("basal_core_occupancy_report", "basal_multi_last_h2d_bytes"):
+            if os.environ.get("BASAL_LIB") and not hasattr(_lib, name) and name in ("basal_core_occupancy_report", "basal_multi_last_h2d_bytes", "basal_core_placement_fork", "basal_core_placement_swap", "basal_core_placement_commit", "basal_core_move_buffers"):
                 continue  # (A/B runs against an older build of the library, tools/run_ab_*.sh: the instrumentation entry points are newer than it)
             f = getattr(_lib, name)
             f.restype = res

@@ -2750,35 +2750,103 @@ extern "C" int basal_core_occupancy_report(char *text, size_t cap) {
     return n;
 }
 
-// Experiment hook (tools/probe_placement.py; not in the header): move one class of the core's long-lived buffers to freshly allocated memory -- new
-// allocation, device copy, the old one freed -- so that its physical placement changes and nothing else. which: 0 locs, 1 flank words, 2 seed words,
-// 3 the two k-mer tables, 4 the reference strands, 5 the per-wave hit logs.
-extern "C" int basal_core_debug_replace(basal_core_t *c, int which) {
-    auto move = [&](void **pp) -> int {
-        if (!*pp) return BASAL_OK;
-        size_t n = 0;
-        HIP_TRY(hipMemPtrGetInfo(*pp, &n));
-        void *q = nullptr;
-        HIP_TRY(hipMalloc(&q, n));
-        HIP_TRY(hipMemcpy(q, *pp, n, hipMemcpyDeviceToDevice));
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(*pp));
-        *pp = q;
-        return BASAL_OK;
-    };
+// Where a buffer lies in HBM is worth up to 10 % of the align kernel's time on a repeat-rich index (steady for a given placement, different
+// from one allocation to the next). The entry points below move the core's long-lived buffers to freshly allocated memory, so that a host with a
+// representative batch can time a launch on two placements and keep the better one (bench.py does). Results do not depend on it. No launch of this core
+// may be in flight. basal_core_move_buffers: one class of buffers -- new allocation, device copy, the old one freed (tools/probe_placement.py).
+namespace {
+int move_buffer(void **pp, bool *moved) {
+    *moved = false;
+    if (!*pp) return BASAL_OK;
+    size_t n = 0;
+    HIP_TRY(hipMemPtrGetInfo(*pp, &n));
+    void *q = nullptr;
+    if (hipMalloc(&q, n) != hipSuccess) { (void)hipGetLastError(); return BASAL_OK; }  // no room for a second copy: it stays where it is
+    HIP_TRY(hipMemcpy(q, *pp, n, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(*pp));
+    *pp = q;
+    *moved = true;
+    return BASAL_OK;
+}
+}  // namespace
+// which: 0 locs, 1 flank words, 2 seed words, 3 the two k-mer tables, 4 the reference strands (and their bit planes), 5 the per-wave hit logs. Returns the
+// number of buffers moved (one that does not fit twice stays), or a negative error.
+extern "C" int basal_core_move_buffers(basal_core_t *c, int which) {
+    if (!c) { g_err = "null argument"; return BASAL_EINVAL; }
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { g_err = "basal_core_move_buffers: device"; return BASAL_EDEVICE; }
+    void **cls[6][4] = {{(void **)&c->d_locs}, {(void **)&c->d_flank_a}, {(void **)&c->d_seedw}, {(void **)&c->d_koff, (void **)&c->d_knfwd},
+                        {(void **)&c->d_xref[0], (void **)&c->d_xref[1], (void **)&c->d_xpl[0], (void **)&c->d_xpl[1]}, {(void **)&c->d_scratch}};
+    if (which < 0 || which > 5) { g_err = "basal_core_move_buffers: which = 0..5"; return BASAL_EINVAL; }
+    int n = 0;
+    for (void **pp : cls[which]) {
+        if (!pp) continue;
+        bool moved = false;
+        const int rc = move_buffer(pp, &moved);
+        if (rc) return rc;
+        n += moved;
+    }
+    if (which == 1) c->d_flank_b = c->d_flank_a ? c->d_flank_a + c->nlocs + 64 : nullptr;
+    return n;
+}
+// A second placement kept beside the first, so that a host can time both and keep the better one:
+//   fork   -- every long-lived buffer copied into freshly allocated memory; the core now runs on the copies, the originals are kept aside.
+//             Returns the number of buffers, or 0 (nothing changed) when HBM has no room for a second set.
+//   swap   -- the core goes back to the set kept aside (and that one becomes the current one).
+//   commit -- the set kept aside is freed.
+namespace {
+constexpr int kPlaced = 10;
+void placed_slots(basal_core *c, void **slot[kPlaced]) {
+    void **s[kPlaced] = {(void **)&c->d_flank_a, (void **)&c->d_locs,    (void **)&c->d_seedw,  (void **)&c->d_koff,   (void **)&c->d_knfwd,
+                         (void **)&c->d_xref[0], (void **)&c->d_xref[1], (void **)&c->d_xpl[0], (void **)&c->d_xpl[1], (void **)&c->d_scratch};
+    for (int i = 0; i < kPlaced; i++) slot[i] = s[i];
+}
+}  // namespace
+extern "C" int basal_core_placement_fork(basal_core_t *c) {
+    if (!c) { g_err = "null argument"; return BASAL_EINVAL; }
+    if (c->alt_valid) { g_err = "basal_core_placement_fork: a second placement is already kept (commit first)"; return BASAL_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    int rc = BASAL_OK;
-    switch (which) {
-    case 0: rc = move((void **)&c->d_locs); break;
-    case 1: rc = move((void **)&c->d_flank_a); c->d_flank_b = c->d_flank_a ? c->d_flank_a + c->nlocs + 64 : nullptr; break;
-    case 2: rc = move((void **)&c->d_seedw); break;
-    case 3: rc = move((void **)&c->d_koff); if (!rc) rc = move((void **)&c->d_knfwd); break;
-    case 4: rc = move((void **)&c->d_xref[0]); if (!rc) rc = move((void **)&c->d_xref[1]); break;
-    case 5: rc = move((void **)&c->d_scratch); break;
-    default: g_err = "basal_core_debug_replace: which = 0..5"; return BASAL_EINVAL;
+    void **slot[kPlaced];
+    placed_slots(c, slot);
+    void *copy[kPlaced] = {};
+    int n = 0;
+    for (int i = 0; i < kPlaced; i++) {
+        if (!*slot[i]) continue;
+        size_t bytes = 0;
+        HIP_TRY(hipMemPtrGetInfo(*slot[i], &bytes));
+        if (hipMalloc(&copy[i], bytes) != hipSuccess) {  // no room for a second set: leave everything as it was
+            (void)hipGetLastError();
+            for (int j = 0; j < i; j++) hipFree(copy[j]);
+            return 0;
+        }
+        HIP_TRY(hipMemcpyAsync(copy[i], *slot[i], bytes, hipMemcpyDeviceToDevice, nullptr));
+        n++;
     }
-    return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < kPlaced; i++) { c->alt[i] = *slot[i]; *slot[i] = copy[i]; }
+    c->d_flank_b = c->d_flank_a ? c->d_flank_a + c->nlocs + 64 : nullptr;
+    c->alt_valid = true;
+    return n;
+}
+extern "C" int basal_core_placement_swap(basal_core_t *c) {
+    if (!c || !c->alt_valid) { g_err = "basal_core_placement_swap: no second placement is kept"; return BASAL_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    void **slot[kPlaced];
+    placed_slots(c, slot);
+    for (int i = 0; i < kPlaced; i++) std::swap(c->alt[i], *slot[i]);
+    c->d_flank_b = c->d_flank_a ? c->d_flank_a + c->nlocs + 64 : nullptr;
+    return BASAL_OK;
+}
+extern "C" int basal_core_placement_commit(basal_core_t *c) {
+    if (!c) { g_err = "null argument"; return BASAL_EINVAL; }
+    if (!c->alt_valid) return BASAL_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < kPlaced; i++) { hipFree(c->alt[i]); c->alt[i] = nullptr; }
+    c->alt_valid = false;
+    return BASAL_OK;
 }
 
 static uint32_t pow3(uint32_t k) {
@@ -2830,6 +2898,7 @@ extern "C" void basal_core_destroy(basal_core_t *c) {
     hipFree(c->d_xref[0]); hipFree(c->d_xref[1]); hipFree(c->d_xpl[0]); hipFree(c->d_xpl[1]); hipFree(c->d_anchor); hipFree(c->d_size); hipFree(c->d_rcoff);
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs); hipFree(c->d_flank_a); hipFree(c->d_seedw); hipFree(c->d_tables); hipFree(c->d_scratch);
     hipFree(c->d_names); hipFree(c->d_name_off);
+    if (c->alt_valid) for (void *q : c->alt) hipFree(q);  // (a second placement still kept aside)
     hipFree(c->d_pe_pairs); hipFree(c->d_pe_recs); hipFree(c->d_pe_work); hipFree(c->d_pe_misc);
     hipFree(c->d_counter);
     c->more_lanes.push_back(&c->lane0);

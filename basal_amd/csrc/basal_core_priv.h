@@ -39,6 +39,8 @@ struct basal_core {
     uint64_t nlocs = 0;
     uint32_t total_kmers = 0, max_kmer_num = 0;
     bool have_ref = false, have_index = false;
+    void *alt[10] = {};      // a second placement of the long-lived buffers kept aside (basal_core_placement_fork / _swap / _commit)
+    bool alt_valid = false;
     bool heavy = false;  // the index keeps long lists (high cut-off): four flank words per entry, HEAVY kernel instantiation (set by basal_build_flanks)
     uint8_t *d_tables = nullptr;
     // work buffers

@@ -309,6 +309,21 @@ int basal_core_align_pairs_batch(basal_core_t *c, const uint8_t *bases, uint64_t
  * number of lines. */
 int basal_core_occupancy_report(char *text, size_t cap);
 
+/* Placement (no reference counterpart): on a repeat-rich index the align kernel's time depends on where hipMalloc put the core's buffers in HBM -- steady
+ * for a given placement, up to 10 % apart between placements. A host with a representative batch can time a launch on two
+ * placements and keep the better one (bench.py does, in its set-up). Results do not depend on any of this; no launch of the core may be in flight.
+ *   basal_core_placement_fork   every long-lived buffer (flank words, locations, seed words, k-mer tables, reference, hit logs) is copied into freshly
+ *                               allocated memory; the core now runs on the copies, the originals are kept aside. Returns the number of buffers copied,
+ *                               0 when HBM has no room for a second set (nothing changed), or a negative error.
+ *   basal_core_placement_swap   back onto the set kept aside (which the current one then becomes).
+ *   basal_core_placement_commit frees the set kept aside.
+ *   basal_core_move_buffers     experiment hook: one class moved (allocation, copy, old one freed): 0 locations, 1 flank words, 2 seed words, 3 k-mer
+ *                               tables, 4 reference, 5 hit logs; returns the buffers moved. */
+int basal_core_placement_fork(basal_core_t *c);
+int basal_core_placement_swap(basal_core_t *c);
+int basal_core_placement_commit(basal_core_t *c);
+int basal_core_move_buffers(basal_core_t *c, int which);
+
 /* ---- several GPUs of one node: reads sharded by read number, hit records gathered with RCCL ----
  * The reference fans batches out to host threads (main.cpp:60-92); this fans the reads of a batch out to GPUs. Every GPU holds the whole
  * reference + index, aligns a contiguous range of the batch's reads, and ONE ncclGather per batch moves the 32-byte records to GPU 0. */

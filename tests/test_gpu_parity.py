@@ -60,6 +60,41 @@ def test_kernels_keep_their_blocks_per_cu():
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("name,heavy", [("rep_r1", "0"), ("rep_r1", "1"), ("rep_g2", "1"), ("long_300", "1")])
+def test_moved_buffers_give_the_same_results(name, heavy, monkeypatch):
+    """basal_core_move_buffers and basal_core_placement_fork / _swap / _commit: every long-lived buffer in fresh memory, class by class and as a second set -- same results."""
+    monkeypatch.setenv("BASAL_HEAVY", heavy)
+    fa, fq, _, _ = H.fixture_paths(name)
+    flags = H.MANIFEST[name]["flags"]
+    p = B.Params(H.rule_of(flags), flags)
+    ref = B.Reference(p, fasta_path=fa)
+    ref.build_index(4)
+    core = B.Core(p)
+    core.upload(ref)
+    recs = H.filter_reads(p, orc.read_fastx(fq))
+    bases, descs, stales = H.make_batch(p, recs, H.StaleTracker(p))
+    L = B.core.lib()
+
+    def run():
+        res, _, _ = core.align_batch(bases, descs, B.STREAM_NONE, stales=stales)  # (the per-read results; the hit stream's order is the atomics')
+        return res.copy().tobytes()
+    want = run()
+    for which in range(6):
+        assert L.basal_core_move_buffers(core.h, which) >= 0, L.basal_last_error()
+        assert run() == want, "after moving buffer class %d" % which
+    assert L.basal_core_placement_swap(core.h) < 0  # nothing kept aside yet
+    assert L.basal_core_placement_fork(core.h) >= 6, L.basal_last_error()
+    assert run() == want, "on the copies"
+    assert L.basal_core_placement_fork(core.h) < 0  # one second set at a time
+    assert L.basal_core_placement_swap(core.h) == 0
+    assert run() == want, "back on the originals"
+    assert L.basal_core_placement_swap(core.h) == 0
+    assert L.basal_core_placement_commit(core.h) == 0
+    assert run() == want, "on the copies, originals freed"
+    assert L.basal_core_placement_fork(core.h) >= 6  # (and a core destroyed with a set kept aside frees both)
+    assert L.basal_core_move_buffers(core.h, 6) < 0
+
+
 @pytest.mark.parametrize("name", H.SE)
 def test_hit_logs_match_oracle(name):
     """Every stored hit of every read, in insertion order, with level/chain/mode: the whole AddHit history."""

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--hold", type=float, default=0.0, help="GB kept allocated from one round to the next (shifts the placement)")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--which", default="", help="comma list of buffer classes to move one at a time (basal_core_debug_replace: 0 locs, 1 flank words, 2 seed words, 3 k-mer tables, 4 reference, 5 hit logs)")
+    ap.add_argument("--which", default="", help="comma list of buffer classes to move one at a time (basal_core_move_buffers: 0 locs, 1 flank words, 2 seed words, 3 k-mer tables, 4 reference, 5 hit logs)")
     ap.add_argument("--pre", type=float, default=0.0, help="GiB allocated (and kept) before the first core is created")
     ap.add_argument("--pair", action="store_true", help="two cores resident at once, launches alternating")
     a = ap.parse_args()
@@ -85,15 +85,13 @@ def main():
 
     if a.which:  # one core; one class of buffers moved at a time: whose placement is it?
         names = ["locs", "flank words", "seed words", "k-mer tables", "reference", "hit logs"]
-        L.basal_core_debug_replace.argtypes = [C.c_void_p, C.c_int]
-        L.basal_core_debug_replace.restype = C.c_int
         core = make_core()
         launch(core)
         print("start: %s" % " ".join("%.2f" % launch(core) for _ in range(a.steps)), flush=True)
         for r in range(a.rounds):
             for w in [int(x) for x in a.which.split(",")]:
-                rc = L.basal_core_debug_replace(core.h, w)
-                if rc:
+                rc = L.basal_core_move_buffers(core.h, w)
+                if rc < 0:
                     print("replace %s failed: %s" % (names[w], L.basal_last_error().decode()), flush=True)
                     continue
                 print("round %d, %s moved: %s" % (r, names[w], " ".join("%.2f" % launch(core) for _ in range(a.steps))), flush=True)
