@@ -312,7 +312,7 @@ def main():
                     help="align against this FASTA (e.g. hg38) instead of a synthetic genome: loaded by the product's loader (basal_host_ref_load), reads are "
                          "sampled from it; default: $BASAL_HG38_FASTA if set")
     ap.add_argument("--contigs", type=int, default=100_000, help="config 3: contigs of the transcriptome stand-in (<= 64: the 24-contig genome-shaped stand-in instead)")
-    ap.add_argument("--placement-draws", type=int, default=int(os.environ.get("BASAL_BENCH_PLACEMENT_DRAWS", "3")),
+    ap.add_argument("--placement-draws", type=int, default=int(os.environ.get("BASAL_BENCH_PLACEMENT_DRAWS", "4")),
                     help="set-up: placements of the index in HBM tried at most (1 = take what hipMalloc gave; see DESIGN section 8)")
     ap.add_argument("--read-len", type=int, default=100, help="read length (the headline workload is 100; 150/300 exercise the 256/480-base kernels)")
     args = ap.parse_args()

@@ -54,7 +54,7 @@ def test_bench_two_gloo_ranks_on_one_gpu():
 
 
 def test_bench_placement_draws_on_a_heavy_index():
-    """bench.py's set-up on an index that keeps long lists (hg38-like genome at scale 0.4: the cut-off passes 32 768 by itself): three placements of the
+    """bench.py's set-up on an index that keeps long lists (hg38-like genome at scale 0.4: the cut-off passes 32 768 by itself): up to four placements of the
     index timed (basal_core_placement_fork / _swap / _commit), the steps on the fastest, the sample still identical to the oracle."""
     env = dict(os.environ, BASAL_BENCH_NO_H2H="1", BASAL_BENCH_NO_UNIFORM="1")
     r = subprocess.run([sys.executable, BENCH, "--genome-scale", "0.4", "--batch", "1000000", "--steps", "2", "--warmup", "1", "--ref-sample", "0", "--cpu-sample", "20000"],
@@ -62,7 +62,7 @@ def test_bench_placement_draws_on_a_heavy_index():
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     draws = d["config"]["placement_draws_ms"]
-    assert len(draws) == 3 and all(t > 0 for t in draws), draws
+    assert 2 <= len(draws) <= 4 and all(t > 0 for t in draws), draws
     assert "HEAVY" in d["roofline"]["kernel"] and "identical to the oracle" in d["cpu_baseline"]["sample"]
     # (the steps' launches -- other batches, copies running beside them -- stay near the best calibration launch, not the worst)
     assert d["roofline"]["kernel_ms"] < min(draws) * 1.10

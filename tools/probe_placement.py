@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--which", default="", help="comma list of buffer classes to move one at a time (basal_core_move_buffers: 0 locs, 1 flank words, 2 seed words, 3 k-mer tables, 4 reference, 5 hit logs)")
     ap.add_argument("--pre", type=float, default=0.0, help="GiB allocated (and kept) before the first core is created")
+    ap.add_argument("--fork", action="store_true", help="every round: a new core timed as built, then on a second set made in one go")
     ap.add_argument("--pair", action="store_true", help="two cores resident at once, launches alternating")
     a = ap.parse_args()
     import torch
@@ -96,6 +97,22 @@ def main():
                     continue
                 print("round %d, %s moved: %s" % (r, names[w], " ".join("%.2f" % launch(core) for _ in range(a.steps))), flush=True)
         core.close()
+        return
+    if a.fork:  # every round: a new core timed as built, then on a second set made in one go (basal_core_placement_fork), the first freed
+        for r in range(a.rounds):
+            core = make_core()
+            launch(core)
+            t0 = [launch(core) for _ in range(a.steps)]
+            n = L.basal_core_placement_fork(core.h)
+            launch(core)
+            t1 = [launch(core) for _ in range(a.steps)]
+            L.basal_core_placement_commit(core.h)
+            n2 = L.basal_core_placement_fork(core.h)
+            launch(core)
+            t2 = [launch(core) for _ in range(a.steps)]
+            print("round %d: as built %s | forked (%d buffers) %s | first set freed, forked again (%d) %s" % (r, " ".join("%.2f" % m for m in t0), n, " ".join("%.2f" % m for m in t1), n2,
+                                                                                                 " ".join("%.2f" % m for m in t2)), flush=True)
+            core.close()
         return
     if a.pair:  # two cores resident at once, launches alternating: placement (A and B differ, each steady) or the clocks (both drift together)?
         for r in range(a.rounds):
