@@ -2807,6 +2807,7 @@ extern "C" int basal_core_placement_fork(basal_core_t *c) {
     if (c->alt_valid) { g_err = "basal_core_placement_fork: a second placement is already kept (commit first)"; return BASAL_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
+    if (int rc = basal_ensure_launch_geometry(c)) return rc;  // (the hit logs exist from here on: both sets have theirs)
     void **slot[kPlaced];
     placed_slots(c, slot);
     void *copy[kPlaced] = {};
@@ -2937,6 +2938,7 @@ extern "C" int basal_core_set_reference(basal_core_t *c, const uint64_t *xref_fw
         g_err = "set_reference: bad argument";
         return BASAL_EINVAL;
     }
+    if (int rc = basal_core_placement_commit(c)) return rc;  // (a second placement kept aside would go stale)
     if ((uint64_t)ref_anchor[ncontig] != (nwords - BASAL_REF_MARGIN) * 32) {
         g_err = "set_reference: ref_anchor[ncontig] does not match nwords (layout: 400 margin words, contigs, 400 margin words)";
         return BASAL_EINVAL;
@@ -2979,6 +2981,7 @@ extern "C" int basal_core_set_index(basal_core_t *c, const uint32_t *kmer_off, c
     if (!c || !kmer_off || !kmer_nfwd || (!locs && nlocs)) { g_err = "set_index: bad argument"; return BASAL_EINVAL; }
     if (nlocs >= 0xFFFFFFFFull) { g_err = "set_index: more than 2^32-1 index entries (the reference's 32-bit counters overflow too)"; return BASAL_EINVAL; }
     if (kmer_off[c->total_kmers] != (uint32_t)nlocs) { g_err = "set_index: kmer_off[3^k] != nlocs"; return BASAL_EINVAL; }
+    if (int rc = basal_core_placement_commit(c)) return rc;  // (a second placement kept aside would go stale)
     HIP_TRY(hipSetDevice(c->device));
     hipFree(c->d_koff); hipFree(c->d_knfwd); hipFree(c->d_locs);
     c->d_koff = c->d_knfwd = c->d_locs = nullptr;

@@ -220,6 +220,7 @@ int basal_build_flanks(basal_core *c, const uint32_t *d_sorted_keys) {
 extern "C" int basal_core_build_index(basal_core_t *c, const uint32_t *blocks, uint64_t nblocks, uint32_t *max_kmer_num_out) {
     if (!c || (!blocks && nblocks)) { set_error("build_index: null argument"); return BASAL_EINVAL; }
     if (!c->have_ref) { set_error("build_index: stage the reference first (basal_core_set_reference)"); return BASAL_ESTATE; }
+    if (int rc = basal_core_placement_commit(c)) return rc;  // (a second placement kept aside would go stale)
     HIP_TRYI(hipSetDevice(c->device));
     const uint32_t K = c->p.seed_size, I = c->p.index_interval, total = c->total_kmers;
     // contig word bases and anchors come from the staged reference
