@@ -3,6 +3,7 @@
 #   gpurun -- 'bash tools/run_pmc.sh r01'     -> gpurun_out/pmc_<tag>/{stats,pmc*}/... and gpurun_out/pmc_<tag>.csv
 # One rocprofv3 pass per counter group (PMC passes never combined with tracing, one program after `--`).
 # The summary (tools/pmc_summary.py) is what gets copied to profiles/.
+export BASAL_BENCH_PLACEMENT_DRAWS=1  # (one placement: the calibration launches of bench.py's placement draws would be averaged into the per-launch figures)
 set -e
 TAG=${1:-run}
 ARGS=${2:---cpu-sample 0 --ref-sample 0 --steps 4}
