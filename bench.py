@@ -465,12 +465,16 @@ def main():
     # gave and on up to --placement-draws - 1 further ones, each time keeping the faster of the two sets. The steps run on the best placement seen.
     placement_ms = []
     if args.placement_draws > 1 and mk.value >= 32768:
-        def calibrate():
-            for _ in range(2):  # (the second launch counts)
-                bc._check(L.basal_core_align_batch_device(core.h, d_bases.data_ptr(), d_reads.data_ptr(), args.batch, None, 0, B.STREAM_NONE, d_results.data_ptr(), None, 0,
-                                                          d_used.data_ptr(), None, read_len, stream), "align_batch_device")
+        def calibrate():  # mean launch time over the pool's batches (each has its own slice of the read and record buffers), after one launch not counted
+            total = 0.0
+            for k, j in enumerate([0] + list(range(n_pool))):
+                bc._check(L.basal_core_align_batch_device(core.h, d_bases.data_ptr() + j * args.batch * read_len, d_reads.data_ptr() + j * args.batch * 16, args.batch, None, 0,
+                                                          B.STREAM_NONE, d_results.data_ptr() + j * args.batch * 32, None, 0, d_used.data_ptr(), None, read_len, stream),
+                          "align_batch_device")
                 torch.cuda.synchronize()
-            return core.kernel_ms()
+                if k:
+                    total += core.kernel_ms()
+            return total / n_pool
 
         best = calibrate()
         placement_ms.append(round(best, 3))
@@ -480,14 +484,18 @@ def main():
                 raise SystemExit("bench: basal_core_placement_fork: " + L.basal_last_error().decode())
             if n_copied == 0:
                 break  # (no room in HBM for a second set)
+            kept = (d_bases, d_reads, d_results)  # the batch's own buffers are part of the placement: second copies of them too
+            d_bases, d_reads, d_results = d_bases.clone(), d_reads.clone(), d_results.clone()
             t = calibrate()
             placement_ms.append(round(t, 3))
             if t < best:
                 best = t
             else:
                 bc._check(L.basal_core_placement_swap(core.h), "placement_swap")  # back onto the faster set
+                d_bases, d_reads, d_results = kept
+            del kept
             bc._check(L.basal_core_placement_commit(core.h), "placement_commit")
-        log("placement draws (calibration launch of %d reads, ms): %s -> %.3f" % (args.batch, placement_ms, best))
+        log("placement draws (mean launch of %d reads over the pool's %d batches, ms): %s -> %.3f" % (args.batch, n_pool, placement_ms, best))
 
     for i in range(args.warmup):
         step(i)
@@ -572,7 +580,7 @@ def main():
     }
     if placement_ms:
         out["config"]["placement_draws_ms"] = placement_ms
-        out["config"]["placement_note"] = ("set-up, not timed: the index was placed in HBM %d time(s) (basal_core_placement_fork / _swap / _commit), a calibration launch of %d reads timed each time; "
+        out["config"]["placement_note"] = ("set-up, not timed: the index was placed in HBM %d time(s) (basal_core_placement_fork / _swap / _commit), the pool's batches of %d reads launched once each time; "
                                            "the steps ran on the fastest of them (DESIGN section 8: the kernel's time follows the placement)" % (len(placement_ms), args.batch))
 
     headline = args.config == "2" and not adhoc and args.read_len == 100 and args.genome_scale == 1.0 and args.genome == "realistic"
