@@ -488,7 +488,11 @@ def main():
             if n_copied == 0:
                 break  # (no room in HBM for a second set)
             kept = (d_bases, d_reads, d_results)  # the batch's own buffers are part of the placement: second copies of them too
-            d_bases, d_reads, d_results = d_bases.clone(), d_reads.clone(), d_results.clone()
+            try:
+                d_bases, d_reads, d_results = d_bases.clone(), d_reads.clone(), d_results.clone()
+            except RuntimeError:  # (no room: the index's second set alone, then)
+                d_bases, d_reads, d_results = kept
+                torch.cuda.empty_cache()
             t = calibrate()
             placement_ms.append(round(t, 3))
             if t < best:
