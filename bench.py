@@ -464,6 +464,8 @@ def main():
     # aside (basal_core_placement_fork), go back (_swap) and free the set not wanted (_commit): a launch of batch 0 is timed on the placement hipMalloc
     # gave and on up to --placement-draws - 1 further ones, each time keeping the faster of the two sets. The steps run on the best placement seen.
     placement_ms = []
+    if world > torch.cuda.device_count():
+        args.placement_draws = 1  # (a rehearsal with several ranks on one GPU: no room for second sets, and another rank's index build may be under way)
     if args.placement_draws > 1 and mk.value >= 32768:
         def calibrate():  # mean launch time over the pool's batches (each has its own slice of the read and record buffers), after one launch not counted
             total = 0.0
